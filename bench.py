@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- RAILS iterations/sec + A*V SpMM HBM GB/s on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one trip of the RAILS loop (src/LyapunovSolver.hpp:136): operator apply on the new columns,
+incremental projection, host projected Lyapunov solve, fused residual Lanczos, convergence test,
+expansion + block orthogonalisation or restart.  Workload (config.workload): BASELINE.json configs[2]
+as defined in SURVEY.md section 8(d): m = 1M rows PER GPU (weak scaling), 27 nnz/row banded-random CSR
+(|j-i| <= 4096), B m x 16, Restart size 200, Reduced size 128, Expand size 16, Lanczos iterations 20,
+synthetic seeded data, fp64.  The tolerance is set so that the timed window never hits convergence (the
+cost of a trip does not depend on it); W warm-up trips run first, then EXACTLY K trips are timed between
+barrier + synchronize on both sides, MAX over ranks.
+
+One JSON line on rank 0 with `roofline` (the CSR x tall-skinny A*V kernel at k = 128 columns, timed live
+with HIP events on the library's stream) and `cpu_baseline` (the CPU oracle, kind "port", on a bounded
+sample of the same workload, rank 0 at N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_problem(args, rank, nranks):
+    from rails_amd import problems as P
+
+    ml = args.m
+    mg = ml * nranks
+    r0 = rank * ml
+    if args.pattern == "banded":
+        rowptr, colg, val = P.banded_random_block(mg, r0, r0 + ml, 27, args.bandwidth, seed=args.seed)
+        desc = "banded-random |j-i|<=%d" % args.bandwidth
+    elif args.pattern == "stencil27":
+        n = round(ml ** (1.0 / 3.0))
+        assert n * n * n == ml, "stencil27 needs a cubic number of rows per GPU"
+        rowptr, colg, val = P.stencil27_block(n, n, n * nranks, rank * n, (rank + 1) * n, random_values=True, seed=args.seed)
+        desc = "27-pt stencil %dx%dx%d random coefficients" % (n, n, n * nranks)
+    elif args.pattern == "uniform":
+        assert nranks == 1, "uniform-random columns are a single-GPU report-only variant"
+        rowptr, col, val = P.uniform_random(ml, 27, seed=args.seed)
+        colg = col.astype(np.int64)
+        desc = "uniform-random columns"
+    elif args.pattern == "laplace7":
+        assert nranks == 1
+        rowptr, col, val = P.laplace7(50, 50, ml // 2500)
+        colg = col.astype(np.int64)
+        desc = "7-pt Laplacian 50x50x%d" % (ml // 2500)
+    else:
+        raise SystemExit("unknown pattern " + args.pattern)
+    B = P.rhs(ml, args.p, seed=args.seed + 7 + rank)
+    return (rowptr, colg, val), B, mg, r0, desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=14)
+    ap.add_argument("--m", type=int, default=1000000, help="rows per GPU")
+    ap.add_argument("--p", type=int, default=16, help="columns of B")
+    ap.add_argument("--pattern", default="banded", choices=["banded", "stencil27", "uniform", "laplace7"])
+    ap.add_argument("--bandwidth", type=int, default=4096)
+    ap.add_argument("--restart", type=int, default=200)
+    ap.add_argument("--reduced", type=int, default=128)
+    ap.add_argument("--expand", type=int, default=16)
+    ap.add_argument("--lanczos", type=int, default=20)
+    ap.add_argument("--kspmm", type=int, default=128, help="columns of the A*V roofline measurement")
+    ap.add_argument("--spmm-reps", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-rows", type=int, default=125000, help="rows of the bounded CPU sample")
+    ap.add_argument("--spmm-variant", type=int, default=0)
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
+    nranks = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if nranks > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import rails_amd
+    from rails_amd import partition
+
+    t_setup = time.time()
+    (rowptr, colg, val), B, mg, r0, desc = build_problem(args, rank, nranks)
+    ml = args.m
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = rails_amd.Context(device=local_rank, stream=stream, seed=args.seed)
+    ctx.set_partition(rank, nranks, r0, mg)
+    if nranks > 1:
+        starts = np.arange(nranks + 1, dtype=np.int64) * ml
+        plan = partition.HaloPlan(starts, rank, colg, partition.all_gather_object_fn())
+        A = rails_amd.HipOperatorWrapper(ctx, rowptr, plan.col_local, val, ncols_ext=ml + plan.n_ghost)
+        A.set_halo(plan, partition.make_halo(plan, on_device=True))
+        ctx.set_allreduce(partition.make_allreduce(on_device=True))
+        halo_rows = plan.n_ghost
+    else:
+        A = rails_amd.HipOperatorWrapper(ctx, rowptr, colg.astype(np.int32), val)
+        halo_rows = 0
+    A.set_variant(args.spmm_variant)
+    nnz_local = int(rowptr[-1])
+    log("[rank %d] setup %.1fs: %s, m_local=%d nnz=%d ghosts=%d" % (rank, time.time() - t_setup, desc, ml, nnz_local, halo_rows))
+
+    # ---- roofline leg: Y = A * X with k = 128 columns, HIP events on the library's stream -------------
+    kk = args.kspmm
+    X = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk)
+    Y = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk)
+    X.random()
+    for _ in range(3):
+        A.apply(X, Y)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(args.spmm_reps):
+        A.apply(X, Y)
+    spmm_ms = ctx.timer_stop() / args.spmm_reps
+    spmm_kernel = A.last_kernel()
+    # algorithmic bytes per launch: nnz*(8+4) + (m+1)*4 + 2*m*k*8
+    alg_bytes = nnz_local * 12 + (ml + 1) * 4 + 2 * ml * kk * 8
+    achieved = alg_bytes / (spmm_ms * 1e-3) / 1e9
+    del X, Y
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("%s:%s" % (spmm_kernel, args.pattern))
+        except Exception:
+            traffic = None
+    log("[rank %d] SpMM %s k=%d: %.3f ms, %.1f GB/s algorithmic (%.1f%% of %.0f GB/s)" % (rank, spmm_kernel, kk, spmm_ms, achieved,
+                                                                                          100 * achieved / HBM_PEAK_GBS, HBM_PEAK_GBS))
+
+    # ---- timed solve ---------------------------------------------------------------------------------
+    W, K = args.warmup, args.steps
+    params = {"Maximum iterations": 100000, "Tolerance": 1e-30, "Expand size": args.expand, "Lanczos iterations": args.lanczos,
+              "Restart size": args.restart, "Reduced size": args.reduced, "Minimize solution space": 0}
+    solver = rails_amd.Solver(ctx, A, B, m_global=mg)
+    code = solver.set_parameters(params)
+    assert code == 0
+    solver.set_option("verbose", 1 if args.verbose else 0)
+    solver.set_option("max_trips", W + K)
+    marks = {}
+
+    def on_trip(trip):
+        if trip == W or trip == W + K:
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            marks[trip] = time.perf_counter()
+
+    solver.set_trip_callback(on_trip)
+    code, _, _ = solver.solve(fetch=False)
+    assert solver.trips() == W + K, "solver stopped after %d trips (code %d)" % (solver.trips(), code)
+    elapsed = marks[W + K] - marks[W]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    its = K / elapsed
+    hist = solver.history()
+    log("[rank %d] %d trips in %.3fs -> %.2f it/s; Lanczos estimates %.3e -> %.3e; V.N()=%d" % (rank, K, elapsed, its, hist[0], hist[-1], solver.k))
+
+    # ---- cpu_baseline: the oracle (port of the Stl path) on a bounded sample, rank 0, N = 1 ---------------
+    cpu = None
+    if rank == 0 and nranks == 1 and not args.no_cpu:
+        from oracle.oracle import Oracle
+        from rails_amd import problems as P
+
+        orc = Oracle()
+        ms = min(args.cpu_rows, ml)
+        if args.pattern == "banded":
+            As = P.banded_random(ms, 27, min(args.bandwidth, ms // 4), seed=args.seed)
+        elif args.pattern == "stencil27":
+            n = round(ms ** (1.0 / 3.0))
+            ms = n * n * n
+            As = P.stencil27(n, n, n, random_values=True, seed=args.seed)
+        elif args.pattern == "laplace7":
+            As = P.laplace7(50, 50, max(1, ms // 2500))
+            ms = As[0].size - 1
+        else:
+            As = P.uniform_random(ms, 27, seed=args.seed)
+        Bs = P.rhs(ms, args.p, seed=args.seed + 7)
+        trips_cpu = W + min(K, 10)
+        prm = orc.params({**params, "rng_mode": 1, "seed": args.seed, "max_trips": trips_cpu})
+        t0 = time.perf_counter()
+        outw = orc.solve(As, Bs, orc.params({**params, "rng_mode": 1, "seed": args.seed, "max_trips": W}), vcap=args.restart + args.expand)
+        t1 = time.perf_counter()
+        out = orc.solve(As, Bs, prm, vcap=args.restart + args.expand)
+        t2 = time.perf_counter()
+        # time of the last (trips_cpu - W) trips = full run - warm-up-only run
+        dt = max((t2 - t1) - (t1 - t0), 1e-9)
+        its_cpu_sample = (trips_cpu - W) / dt
+        cpu = {"value": its_cpu_sample * ms / ml, "unit": "iterations/s", "cores": orc.num_threads(), "kind": "port",
+               "sample": "oracle (CPU restatement of the Stl path, OpenMP) on the same workload restricted to %d rows: trips %d..%d timed "
+                         "(%.2f it/s on the sample), scaled by %d/%d rows to the full size" % (ms, W + 1, trips_cpu, its_cpu_sample, ms, ml)}
+        log("[cpu] sample %d rows: %.2f it/s -> scaled %.3f it/s on %d threads" % (ms, its_cpu_sample, cpu["value"], orc.num_threads()))
+
+    if rank == 0:
+        line = {
+            "metric": "RAILS iterations/sec (+ A*V SpMM HBM GB/s in roofline), m=1M rows/GPU, k=128, fp64",
+            "value": its, "unit": "iterations/s", "n_gpus": nranks, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: m=%d rows/GPU (global %d), 27 nnz/row %s CSR, B m x %d, Restart size %d, Reduced size %d, "
+                                   "Expand size %d, Lanczos iterations %d" % (ml, mg, desc, args.p, args.restart, args.reduced, args.expand, args.lanczos),
+                       "parallelism": "row-partition x%d, RCCL all-reduce of projected blocks" % nranks if nranks > 1 else "single GPU",
+                       "spmm_columns": kk},
+            "roofline": {"bound": "hbm", "kernel": spmm_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,210 @@
+/* ============================================================================
+ * rails_hip.h -- C ABI of librails_hip.so: the MI355X (gfx950) back end of the
+ * RAILS inner loop.
+ *
+ * This is the drop-in boundary.  The reference (Sbte/RAILS) has no FFI: its
+ * plug-in seam is C++ template duck typing, Solver<Matrix, MultiVector,
+ * DenseMatrix> (src/LyapunovSolverDecl.hpp:9-51).  The header-only wrappers in
+ * rails_amd/include/rails/ (HipOperatorWrapper, HipMultiVectorWrapper,
+ * HostDenseMatrix) satisfy that contract and are implemented purely in terms of
+ * the entry points below, so this C ABI is exactly what a binding for the hot
+ * path binds.  Each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative RAILS_E* code otherwise
+ *     (never throws); rails_last_error() gives the message of the calling
+ *     thread's last failure.  This mirrors the reference's "no exceptions, int
+ *     codes, message on stderr" behaviour (src/StlWrapper.cpp:173-179).
+ *   - host matrices cross the boundary COLUMN-MAJOR with a leading dimension,
+ *     like the reference's StlWrapper / DenseMatrix storage
+ *     (src/StlVector.cpp:47-50, operator double* at src/StlWrapper.cpp:201).
+ *   - device panels are ROW-MAJOR m_local x ld (ld = padded column capacity):
+ *     one sparse nonzero gathers one contiguous row segment, reductions run
+ *     down the slow index, and view/resize/push_back are O(1) column-window
+ *     changes.  The solver never sees MultiVector memory
+ *     (src/LyapunovSolver.hpp uses double* only from DenseMatrix, :357,:458),
+ *     so the layout is free.
+ *   - the library owns device buffers until *_destroy; the caller owns host
+ *     buffers.  Calls that return host values are synchronisation points;
+ *     everything else is asynchronous on the context's stream.
+ *   - row-partitioned multi-GPU runs: every rank holds a contiguous block of
+ *     rows of A, V, AV, B; small (k x k, p x k) objects are replicated.  All
+ *     reductions over rows go through the all-reduce hook (sum of doubles).
+ * ==========================================================================*/
+#ifndef RAILS_HIP_H
+#define RAILS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAILS_OK 0
+#define RAILS_EINVAL -1   /* bad argument / shape mismatch                      */
+#define RAILS_EHIP -2     /* a HIP runtime call failed                          */
+#define RAILS_ENOMEM -3   /* device or host allocation failed                   */
+#define RAILS_ELAPACK -4  /* host LAPACK missing or returned an error           */
+#define RAILS_ECOMM -5    /* all-reduce / halo hook failed                      */
+#define RAILS_ENODEV -6   /* no usable gfx950 device                            */
+
+typedef struct rails_ctx rails_ctx;     /* device, stream, workspaces, RNG, collectives */
+typedef struct rails_csr rails_csr;     /* device CSR operator (the Matrix role)        */
+typedef struct rails_panel rails_panel; /* device row-partitioned panel (MultiVector)   */
+
+const char *rails_last_error(void);
+const char *rails_version(void);
+
+/* ---------------------------------------------------------------- context --- */
+
+/* device: HIP device ordinal.  stream: a hipStream_t to run on (e.g. the caller's
+ * torch stream), or NULL to let the library create its own. */
+int rails_ctx_create(int device, void *stream, rails_ctx **out);
+int rails_ctx_destroy(rails_ctx *ctx);
+int rails_ctx_sync(rails_ctx *ctx);
+void *rails_ctx_stream(rails_ctx *ctx);
+
+/* Counter-based RNG: value = f(seed, stream id, GLOBAL row, column); every random
+ * fill consumes one stream id.  Replaces StlWrapper::random's std::rand()-seeded
+ * generator (src/StlWrapper.cpp:414-423) by one that is identical on CPU and GPU
+ * and independent of the row partition. */
+int rails_ctx_set_seed(rails_ctx *ctx, uint64_t seed, uint64_t first_stream);
+
+/* Row partition of this rank: local rows are global rows [row0, row0 + m_local). */
+int rails_ctx_set_partition(rails_ctx *ctx, int rank, int nranks, int64_t row0, int64_t m_global);
+
+/* Sum-all-reduce hook over the ranks, in place on a DEVICE buffer of n doubles,
+ * ordered on `stream`.  With nranks == 1 no hook is needed.  This is the one
+ * collective of the path: Epetra hides it in Multiply('T','N')/Norm2
+ * (src/Epetra_MultiVectorWrapper.cpp:238,312,431). */
+typedef int (*rails_allreduce_fn)(void *user, double *dev_buf, size_t n, void *stream);
+int rails_ctx_set_allreduce(rails_ctx *ctx, rails_allreduce_fn fn, void *user);
+
+/* Halo hook for the row-partitioned operator apply: given the packed rows this rank
+ * must send (send_buf, concatenated per destination rank as described by the counts
+ * passed to rails_csr_set_halo) fill recv_buf with the ghost rows, on `stream`.
+ * Replaces the import inside Epetra_CrsMatrix::Apply (src/Epetra_OperatorWrapper.cpp:87). */
+typedef int (*rails_halo_fn)(void *user, const double *send_buf, double *recv_buf, int ncols, void *stream);
+
+/* ------------------------------------------------------------ CSR operator --- */
+
+/* Upload a local CSR block: m_local rows, column indices in [0, n_cols_ext) where
+ * columns [0, m_local) are the local rows and [m_local, n_cols_ext) are ghost rows
+ * (n_cols_ext == m_local on one GPU).  rowptr has m_local+1 entries.
+ * Role: the Matrix template parameter (src/LyapunovSolverDecl.hpp:37,
+ * Epetra_OperatorWrapper.cpp:75-91; StlWrapper.cpp:168-187 for the dense Stl form). */
+int rails_csr_create(rails_ctx *ctx, int64_t m_local, int64_t n_cols_ext, const int64_t *rowptr,
+                     const int32_t *col, const double *val, rails_csr **out);
+int rails_csr_destroy(rails_csr *A);
+int64_t rails_csr_rows(const rails_csr *A);
+int64_t rails_csr_nnz(const rails_csr *A);
+
+/* Ghost-row plan for multi-GPU: send_rows[0..n_send) are LOCAL row indices to pack (in
+ * the order the halo hook expects), n_ghost rows are received. */
+int rails_csr_set_halo(rails_csr *A, int64_t n_send, const int64_t *send_rows, int64_t n_ghost,
+                       rails_halo_fn fn, void *user);
+
+/* Y[:, yc0:yc0+nc] = op(A) * X[:, xc0:xc0+nc]; trans != 0 applies A^T (single GPU only).
+ * Replaces `A_ * W` (src/LyapunovSolver.hpp:146).  X and Y must not alias. */
+int rails_spmm(rails_ctx *ctx, rails_csr *A, int trans, const rails_panel *X, int xc0, int nc,
+               rails_panel *Y, int yc0);
+
+/* Kernel variant control for benchmarking: 0 = auto, 1 = row-gather kernel,
+ * 2 = LDS-staged footprint kernel. */
+int rails_csr_set_variant(rails_csr *A, int variant);
+/* name of the kernel the last rails_spmm on A launched */
+const char *rails_csr_last_kernel(const rails_csr *A);
+
+/* ------------------------------------------------------------------ panels --- */
+
+/* A panel holds m_local rows x capacity columns (ld >= capacity, padded).
+ * Role: the MultiVector template parameter's storage (StlWrapper m_max x n_max buffer,
+ * src/StlWrapper.hpp:13-21). */
+int rails_panel_create(rails_ctx *ctx, int64_t m_local, int capacity, rails_panel **out);
+int rails_panel_destroy(rails_panel *P);
+int64_t rails_panel_rows(const rails_panel *P);
+int rails_panel_capacity(const rails_panel *P);
+int rails_panel_ld(const rails_panel *P);
+void *rails_panel_device_ptr(const rails_panel *P);
+/* grow capacity preserving contents (StlWrapper::resize re-allocation, src/StlWrapper.cpp:238-248) */
+int rails_panel_reserve(rails_ctx *ctx, rails_panel *P, int capacity);
+
+/* host (column-major, ldh) <-> device columns [c0, c0+nc) */
+int rails_panel_upload(rails_ctx *ctx, rails_panel *P, int c0, int nc, const double *host, int64_t ldh);
+int rails_panel_download(rails_ctx *ctx, const rails_panel *P, int c0, int nc, double *host, int64_t ldh);
+
+int rails_panel_fill(rails_ctx *ctx, rails_panel *P, int c0, int nc, double value);     /* operator=(double) :123 */
+int rails_panel_scale(rails_ctx *ctx, rails_panel *P, int c0, int nc, double s);        /* operator*=  :131      */
+int rails_panel_copy(rails_ctx *ctx, const rails_panel *X, int xc0, int nc, rails_panel *Y, int yc0); /* = / push_back :65,:367 */
+int rails_panel_axpy(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int nc, rails_panel *Y,
+                     int yc0);                                                            /* += -=  :145-158        */
+int rails_panel_random(rails_ctx *ctx, rails_panel *P, int c0, int nc);                  /* random() :414         */
+
+/* C (a x b, host, column-major ldc) = X[:, xc0:+a]^T * Y[:, yc0:+b], summed over all ranks.
+ * Replaces MultiVector::dot (src/StlWrapper.cpp:394-412; call sites
+ * src/LyapunovSolver.hpp:173,187,394,400,406).  Synchronises. */
+int rails_gram(rails_ctx *ctx, const rails_panel *X, int xc0, int a, const rails_panel *Y, int yc0, int b,
+               double *C_host, int ldc);
+
+/* Y[:, yc0:+r] = beta * Y[:, yc0:+r] + alpha * X[:, xc0:+k] * C   (C host, k x r column-major).
+ * Replaces MultiVector * DenseMatrix (src/StlWrapper.cpp:168-187; call sites
+ * src/LyapunovSolver.hpp:265,290,396,402,443).  X and Y may be the same panel only if the
+ * column windows coincide exactly (in-place, row-local) or are disjoint. */
+int rails_panel_gemm(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int k, const double *C_host,
+                     int ldc, int r, double beta, rails_panel *Y, int yc0);
+
+/* Orthonormalise columns [k_old, k_old+w) of V against columns [0, k_old) and among themselves,
+ * equivalent to the reference's column-wise CGS2 with pre/post normalisation
+ * (src/StlWrapper.cpp:305-321): block CGS2 + CholQR2 on MFMA, falling back to the column-wise
+ * form when the block Gram matrix is numerically rank deficient.  method: 0 = auto,
+ * 1 = force column-wise, 2 = force block.  *used (may be NULL) receives the method used. */
+int rails_orthogonalize(rails_ctx *ctx, rails_panel *V, int k_old, int w, int method, int *used);
+
+/* Fused residual Lanczos (src/LyapunovSolver.hpp:367-447): L steps of Lanczos on the implicit
+ *   R = AV*T*MV^T + MV*T*AV^T + B*B^T      (MV == V for M = I)
+ * started from a fresh random unit vector (one RNG stream is consumed, as Q.random() does at :374).
+ * One pass over [AV MV B] per step; alpha, beta and the breakdown test stay on the device.
+ *   T_host: k x k column-major (ldt).  H_host: out, (L+1) x (L+1) column-major (ldh >= L+1),
+ *   zero-filled then the tridiagonal entries set exactly where the reference sets them.
+ *   *steps: Lanczos steps done (< L on breakdown, beta < 1e-14, :419-426).
+ * The orthonormal Lanczos vectors q_0..q_{steps-1} stay in a device side buffer of the library until the
+ * next call.  Column windows must start at even columns; k <= 512, p <= 128.  Synchronises. */
+int rails_resid_lanczos(rails_ctx *ctx, const rails_panel *AV, int avc0, const rails_panel *MV, int mvc0, int k,
+                        const double *T_host, int ldt, const rails_panel *B, int bc0, int p, int L,
+                        double *H_host, int ldh, int *steps);
+
+/* Out[:, oc0:oc0+w] = Q * S with Q the Lanczos vectors of the last rails_resid_lanczos and S (steps x w,
+ * host column-major, lds).  Replaces `eigenvectors = Q * v` (src/LyapunovSolver.hpp:443); passing only the
+ * selected columns of v writes the expansion vectors straight into V's tail (:338-339). */
+int rails_lanczos_vectors(rails_ctx *ctx, const double *S_host, int lds, int w, rails_panel *Out, int oc0);
+int rails_lanczos_release(void);
+
+/* ---------------------------------------------------------- timing helpers --- */
+/* HIP-event timing on the context's stream (bench.py's roofline leg). */
+int rails_timer_start(rails_ctx *ctx);
+int rails_timer_stop(rails_ctx *ctx, double *ms);
+
+/* ------------------------------------------------------ host numerics (C ABI) --- */
+/* Kept on the host per the north star; thin C ABI with the argument meaning of the reference's
+ * shims.  LAPACK is resolved at run time (env RAILS_LAPACK_LIB, scipy's OpenBLAS, MKL, system). */
+
+/* src/SlicotWrapper.hpp:14-16.  Only (dico,job,fact) = ('C','X','N') is supported (the only use,
+ * src/LyapunovSolver.hpp:357).  trans='T' solves A*X + X*A^T = scale*C, trans='N' A^T*X + X*A.
+ * SLICOT itself is not available: Bartels-Stewart on dgees + dtrsyl; info = n+1 when the
+ * triangular solve had to perturb (SLICOT's convention). */
+void rails_sb03md(char dico, char job, char fact, char trans, int n, double *A, int lda, double *X, int ldx,
+                  double *scale, int *info);
+/* src/LapackWrapper.hpp:21-22 */
+void rails_dsyev(char jobz, char uplo, int n, double *a, int lda, double *w, int *info);
+/* src/LapackWrapper.hpp:18-19 */
+void rails_dsteqr(char compz, int n, double *d, double *e, double *z, int ldz, double *work, int *info);
+/* Cholesky (generalized projected solve, block orthogonalisation) */
+void rails_dpotrf(char uplo, int n, double *a, int lda, int *info);
+int rails_host_lapack_init(const char *path);
+const char *rails_host_lapack_path(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAILS_HIP_H */

@@ -1,0 +1,317 @@
+// dense.hip -- tall-skinny dense kernels on v_mfma_f64_16x16x4_f64 (gfx950):
+//   rails_gram        C = X^T Y          (MultiVector::dot,  src/StlWrapper.cpp:394-412)
+//   rails_panel_gemm  Y = beta Y + alpha X C   (MultiVector * DenseMatrix, src/StlWrapper.cpp:168-187)
+//
+// fp64 MFMA on gfx950 runs at the fp64 vector rate; it is used here because it needs ONE operand
+// register per lane per 2048 flop (no LDS broadcast of the small operand, no register tiling),
+// which leaves the load path free: both kernels are HBM-bound whenever one small dimension is
+// <= 32 (every call of the solver) and reach the fp64 ridge only for k x 128 restart products.
+//
+// MFMA f64 16x16x4 lane maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&15][k=l>>4]
+// and B[k=l>>4][j=l&15]; it receives D[row=(l>>4)+4*v][col=l&15] in result register v (0..3).
+//
+// Reductions over rows are two-stage and deterministic: per-block partial tiles are written to a
+// workspace and summed in a fixed order by a second kernel (no float atomics), then all-reduced
+// over the ranks through the context hook.
+#include "rails_internal.h"
+
+#include <algorithm>
+
+namespace {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v4f64 mfma_f64(double a, double b, v4f64 c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------- Gram ---
+// grid.x = row slabs, grid.y = tile groups (gi over X column tiles, gj over Y column tiles).
+// Each of the 4 waves accumulates TI x TJ output tiles over its share of the slab's rows.
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) void k_gram(const double *__restrict__ X, int ldx, int a, const double *__restrict__ Y, int ldy,
+                                              int b, int64_t m, int64_t rows_per_slab, int ngj, double *__restrict__ partial)
+{
+    __shared__ double red[TI * TJ * 256];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int gi = blockIdx.y / ngj, gj = blockIdx.y % ngj;
+    const int xcol0 = gi * TI * 16, ycol0 = gj * TJ * 16;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_slab;
+    int64_t r_end = r_begin + rows_per_slab;
+    if (r_end > m) r_end = m;
+
+    v4f64 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    bool xok[TI], yok[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) xok[i] = (xcol0 + 16 * i + li) < a;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) yok[j] = (ycol0 + 16 * j + li) < b;
+
+    for (int64_t r = r_begin + 4 * wave; r < r_end; r += 16) {
+        const int64_t row = r + kk;
+        const bool rok = row < r_end;
+        double xa[TI], yb[TJ];
+        const double *xr = X + row * ldx + xcol0 + li;
+        const double *yr = Y + row * ldy + ycol0 + li;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) xa[i] = (rok && xok[i]) ? xr[16 * i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) yb[j] = (rok && yok[j]) ? yr[16 * j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = mfma_f64(xa[i], yb[j], acc[i][j]);
+    }
+
+    // cross-wave reduction in a fixed order (wave 0 += wave 1, 2, 3)
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) red[((i * TJ + j) * 4 + v) * 64 + lane] = acc[i][j][v];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[i][j][v] += red[((i * TJ + j) * 4 + v) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        double *P = partial + (int64_t)blockIdx.x * a * b;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    int ci = xcol0 + 16 * i + kk + 4 * v; // D row  -> X column
+                    int cj = ycol0 + 16 * j + li;         // D col  -> Y column
+                    if (ci < a && cj < b) P[ci + (int64_t)cj * a] = acc[i][j][v];
+                }
+    }
+}
+
+__global__ void k_reduce_partials(const double *__restrict__ partial, int64_t nslab, int64_t n, double *__restrict__ out)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int64_t t = 0; t < nslab; ++t) s += partial[t * n + e];
+    out[e] = s;
+}
+
+template <int TI, int TJ>
+void launch_gram(rails_ctx *c, const double *X, int ldx, int a, const double *Y, int ldy, int b, int64_t m, int64_t rps,
+                 int64_t nslab, double *partial)
+{
+    int ngi = (a + 16 * TI - 1) / (16 * TI), ngj = (b + 16 * TJ - 1) / (16 * TJ);
+    hipLaunchKernelGGL((k_gram<TI, TJ>), dim3((unsigned)nslab, (unsigned)(ngi * ngj)), dim3(256), 0, c->stream, X, ldx, a, Y, ldy, b,
+                       m, rps, ngj, partial);
+}
+
+// ------------------------------------------------------------------------- panel GEMM ---
+// Each wave owns 16 rows and all r (<= 16*TR) output columns; the block streams C through LDS in
+// chunks of KC rows.  X is read with the k index permuted inside every 16-column block so that a
+// lane reads 4 consecutive doubles: lane (i,kk) holds X[row i][kb + 4*kk + s], s = 0..3, and MFMA
+// number s sums over k in {kb + 4*kk + s}; C's rows are fetched from LDS with the same permutation.
+template <int TR, int KC>
+__global__ __launch_bounds__(256) void k_panel_gemm(double alpha, const double *X, int ldx, int k,
+                                                    const double *__restrict__ C, int r, double beta, double *Yp,
+                                                    int ldy, int64_t m, int vec_ok)
+{
+    constexpr int RL = 16 * TR + 4; // LDS row length (doubles): +4 keeps the 4 k-groups on disjoint banks
+    __shared__ double Cs[KC * RL];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    const int64_t myrow = r0 + li;
+    const bool rowok = myrow < m;
+
+    v4f64 acc[TR];
+#pragma unroll
+    for (int t = 0; t < TR; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    const double *xrow = X + myrow * ldx;
+    for (int kc = 0; kc < k; kc += KC) {
+        __syncthreads();
+        // stage C[kc:kc+KC, 0:r) (col-major, ld = k) into LDS row-major, zero padded
+        for (int idx = threadIdx.x; idx < KC * 16 * TR; idx += 256) {
+            int kl = idx % KC, j = idx / KC;
+            double v = 0.0;
+            if (kc + kl < k && j < r) v = C[(kc + kl) + (int64_t)j * k];
+            Cs[kl * RL + j] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < KC; kb += 16) {
+            const int kcol = kc + kb + 4 * kk;
+            double xs[4];
+            if (rowok && vec_ok && kcol + 4 <= k) {
+                v2f64 t0 = *reinterpret_cast<const v2f64 *>(xrow + kcol);
+                v2f64 t1 = *reinterpret_cast<const v2f64 *>(xrow + kcol + 2);
+                xs[0] = t0.x;
+                xs[1] = t0.y;
+                xs[2] = t1.x;
+                xs[3] = t1.y;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xs[s] = (rowok && kcol + s < k) ? xrow[kcol + s] : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double *crow = &Cs[(kb + 4 * kk + s) * RL + li];
+#pragma unroll
+                for (int t = 0; t < TR; ++t) acc[t] = mfma_f64(xs[s], crow[16 * t], acc[t]);
+            }
+        }
+    }
+    // D[row = kk + 4v][col = li]
+#pragma unroll
+    for (int t = 0; t < TR; ++t) {
+        const int j = 16 * t + li;
+        if (j >= r) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t row = r0 + kk + 4 * v;
+            if (row >= m) continue;
+            double *dst = Yp + row * ldy + j;
+            double val = alpha * acc[t][v];
+            if (beta != 0.0) val += beta * (*dst);
+            *dst = val;
+        }
+    }
+}
+
+template <int TR, int KC>
+void launch_pg(rails_ctx *c, double alpha, const double *X, int ldx, int k, const double *C, int r, double beta, double *Y,
+               int ldy, int64_t m, int vec_ok)
+{
+    int64_t grid = (m + 63) / 64;
+    hipLaunchKernelGGL((k_panel_gemm<TR, KC>), dim3((unsigned)grid), dim3(256), 0, c->stream, alpha, X, ldx, k, C, r, beta, Y,
+                       ldy, m, vec_ok);
+}
+
+} // namespace
+
+int rails_gram_dev(rails_ctx *c, const double *X, int ldx, const double *Y, int ldy, int64_t m, int a, int b, double *C_dev)
+{
+    if (a <= 0 || b <= 0) return RAILS_OK;
+    // slab count: enough blocks to fill the chip, partial-tile traffic bounded to ~4% of the input
+    double bound = 0.02 * (double)m * (double)(a + b) / ((double)a * (double)b);
+    int64_t nslab = (int64_t)std::min<double>(1024.0, std::max<double>(1.0, bound));
+    int64_t maxslab = (m + 15) / 16;
+    if (nslab > maxslab) nslab = std::max<int64_t>(1, maxslab);
+    int64_t rps = (m + nslab - 1) / nslab;
+    rps = (rps + 15) / 16 * 16;
+    if (rps < 16) rps = 16;
+    nslab = std::max<int64_t>(1, (m + rps - 1) / rps);
+    size_t n = (size_t)a * b;
+    RAILS_TRY(rails_ws_reserve(c, (size_t)nslab * n * sizeof(double)));
+    if (b <= 16 && a <= 16)
+        launch_gram<1, 1>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
+    else if (b <= 16)
+        launch_gram<8, 1>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
+    else if (a <= 16)
+        launch_gram<1, 8>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
+    else if (b <= 32)
+        launch_gram<4, 2>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
+    else if (a <= 32)
+        launch_gram<2, 4>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
+    else
+        launch_gram<2, 4>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->ws, nslab, (int64_t)n, C_dev);
+    RAILS_HIP_CHECK(hipGetLastError());
+    return RAILS_OK;
+}
+
+extern "C" int rails_gram(rails_ctx *c, const rails_panel *X, int xc0, int a, const rails_panel *Y, int yc0, int b, double *C_host,
+                          int ldc)
+{
+    RAILS_REQUIRE(c && X && Y, "rails_gram: null argument");
+    RAILS_REQUIRE(a >= 0 && b >= 0 && xc0 >= 0 && yc0 >= 0 && xc0 + a <= X->cap && yc0 + b <= Y->cap,
+                  "rails_gram: windows [%d,%d) / [%d,%d) outside capacities %d / %d", xc0, xc0 + a, yc0, yc0 + b, X->cap, Y->cap);
+    RAILS_REQUIRE(X->m == Y->m, "rails_gram: row mismatch %lld vs %lld", (long long)X->m, (long long)Y->m);
+    RAILS_REQUIRE(a == 0 || b == 0 || (C_host && ldc >= a), "rails_gram: bad output buffer (ldc %d < %d)", ldc, a);
+    if (a == 0 || b == 0) return RAILS_OK;
+    size_t n = (size_t)a * b;
+    RAILS_TRY(rails_small_reserve(c, n * sizeof(double)));
+    RAILS_TRY(rails_pinned_reserve(c, n * sizeof(double)));
+    if (X->m > 0)
+        RAILS_TRY(rails_gram_dev(c, X->d + xc0, X->ld, Y->d + yc0, Y->ld, X->m, a, b, c->small));
+    else
+        RAILS_HIP_CHECK(hipMemsetAsync(c->small, 0, n * sizeof(double), c->stream));
+    RAILS_TRY(rails_allreduce_dev(c, c->small, n));
+    RAILS_HIP_CHECK(hipMemcpyAsync(c->pinned, c->small, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < b; ++j) memcpy(C_host + (size_t)j * ldc, c->pinned + (size_t)j * a, sizeof(double) * a);
+    return RAILS_OK;
+}
+
+int rails_panel_gemm_dev(rails_ctx *c, double alpha, const double *X, int ldx, int k, const double *C_dev, int r, double beta,
+                         double *Y, int ldy, int64_t m)
+{
+    if (r <= 0 || m <= 0) return RAILS_OK;
+    int vec_ok = ((((uintptr_t)X) & 15) == 0 && (ldx % 2) == 0) ? 1 : 0;
+    int tr = (r + 15) / 16;
+    if (tr <= 1)
+        launch_pg<1, 32>(c, alpha, X, ldx, k, C_dev, r, beta, Y, ldy, m, vec_ok);
+    else if (tr <= 2)
+        launch_pg<2, 32>(c, alpha, X, ldx, k, C_dev, r, beta, Y, ldy, m, vec_ok);
+    else if (tr <= 4)
+        launch_pg<4, 32>(c, alpha, X, ldx, k, C_dev, r, beta, Y, ldy, m, vec_ok);
+    else if (tr <= 8)
+        launch_pg<8, 32>(c, alpha, X, ldx, k, C_dev, r, beta, Y, ldy, m, vec_ok);
+    else
+        launch_pg<16, 16>(c, alpha, X, ldx, k, C_dev, r, beta, Y, ldy, m, vec_ok);
+    RAILS_HIP_CHECK(hipGetLastError());
+    return RAILS_OK;
+}
+
+extern "C" int rails_panel_gemm(rails_ctx *c, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc,
+                                int r, double beta, rails_panel *Y, int yc0)
+{
+    RAILS_REQUIRE(c && X && Y, "rails_panel_gemm: null argument");
+    RAILS_REQUIRE(k >= 0 && r >= 0 && xc0 >= 0 && yc0 >= 0 && xc0 + k <= X->cap && yc0 + r <= Y->cap,
+                  "rails_panel_gemm: windows [%d,%d) / [%d,%d) outside capacities %d / %d", xc0, xc0 + k, yc0, yc0 + r, X->cap, Y->cap);
+    RAILS_REQUIRE(X->m == Y->m, "rails_panel_gemm: row mismatch %lld vs %lld", (long long)X->m, (long long)Y->m);
+    RAILS_REQUIRE(r <= 256, "rails_panel_gemm: r = %d > 256 output columns per call", r);
+    RAILS_REQUIRE(k == 0 || r == 0 || (C_host && ldc >= k), "rails_panel_gemm: bad coefficient matrix (ldc %d < %d)", ldc, k);
+    if (X->d == Y->d) {
+        bool same = (xc0 == yc0);
+        bool disjoint = (xc0 + k <= yc0) || (yc0 + r <= xc0);
+        RAILS_REQUIRE(same || disjoint, "rails_panel_gemm: partially overlapping windows of one panel");
+    }
+    if (r == 0 || X->m == 0) return RAILS_OK;
+    if (k == 0) {
+        if (beta == 0.0) return rails_panel_fill(c, Y, yc0, r, 0.0);
+        if (beta == 1.0) return RAILS_OK;
+        return rails_panel_scale(c, Y, yc0, r, beta);
+    }
+    size_t n = (size_t)k * r;
+    RAILS_TRY(rails_small_reserve(c, n * sizeof(double)));
+    RAILS_TRY(rails_pinned_reserve(c, n * sizeof(double)));
+    for (int j = 0; j < r; ++j) memcpy(c->pinned + (size_t)j * k, C_host + (size_t)j * ldc, sizeof(double) * k);
+    RAILS_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RAILS_TRY(rails_panel_gemm_dev(c, alpha, X->d + xc0, X->ld, k, c->small, r, beta, Y->d + yc0, Y->ld, X->m));
+    // the pinned staging buffer is reused by the next call: make sure the copy has been consumed
+    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RAILS_OK;
+}

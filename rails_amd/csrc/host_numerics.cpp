@@ -1,0 +1,205 @@
+// host_numerics.cpp -- the small dense solves that stay on the host (north star): thin C ABI with
+// the argument meaning of the reference's shims
+//   rails_sb03md  <- RAILS::sb03md      (src/SlicotWrapper.hpp:14-16, src/SlicotWrapper.cpp:8-49)
+//   rails_dsyev   <- LapackWrapper::DSYEV  (src/LapackWrapper.cpp:20-39)
+//   rails_dsteqr  <- LapackWrapper::DSTEQR (src/LapackWrapper.cpp:12-18)
+// LAPACK is resolved at run time with dlopen (the GPU box carries no system LAPACK; this image
+// ships scipy's OpenBLAS and MKL).  SLICOT is not available anywhere in the image, so the
+// continuous Lyapunov solve is a Bartels-Stewart implementation on dgees + dtrsyl.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rails_hip.h"
+
+void rails_set_error(const char *fmt, ...);
+
+namespace {
+
+extern "C" {
+typedef int (*lp_select2)(const double *, const double *);
+typedef void (*lp_dsyev)(const char *, const char *, const int *, double *, const int *, double *, double *, const int *, int *);
+typedef void (*lp_dsteqr)(const char *, const int *, double *, double *, double *, const int *, double *, int *);
+typedef void (*lp_dgees)(const char *, const char *, lp_select2, const int *, double *, const int *, int *, double *, double *,
+                         double *, const int *, double *, const int *, int *, int *);
+typedef void (*lp_dtrsyl)(const char *, const char *, const int *, const int *, const int *, const double *, const int *,
+                          const double *, const int *, double *, const int *, double *, int *);
+typedef void (*lp_dpotrf)(const char *, const int *, double *, const int *, int *);
+typedef void (*lp_dgemm)(const char *, const char *, const int *, const int *, const int *, const double *, const double *,
+                         const int *, const double *, const int *, const double *, double *, const int *);
+}
+
+struct HostLapack {
+    void *handle = nullptr;
+    std::string path;
+    lp_dsyev dsyev = nullptr;
+    lp_dsteqr dsteqr = nullptr;
+    lp_dgees dgees = nullptr;
+    lp_dtrsyl dtrsyl = nullptr;
+    lp_dpotrf dpotrf = nullptr;
+    lp_dgemm dgemm = nullptr;
+} g_lp;
+std::mutex g_lp_mutex;
+
+void *lookup(void *h, const char *base)
+{
+    static const char *prefixes[] = {"scipy_", "", nullptr};
+    for (int i = 0; prefixes[i]; ++i) {
+        std::string s = std::string(prefixes[i]) + base;
+        if (void *p = dlsym(h, s.c_str())) return p;
+    }
+    return nullptr;
+}
+
+bool try_open(const std::string &path)
+{
+    if (path.empty()) return false;
+    void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) return false;
+    HostLapack L;
+    L.handle = h;
+    L.path = path;
+    L.dsyev = (lp_dsyev)lookup(h, "dsyev_");
+    L.dsteqr = (lp_dsteqr)lookup(h, "dsteqr_");
+    L.dgees = (lp_dgees)lookup(h, "dgees_");
+    L.dtrsyl = (lp_dtrsyl)lookup(h, "dtrsyl_");
+    L.dpotrf = (lp_dpotrf)lookup(h, "dpotrf_");
+    L.dgemm = (lp_dgemm)lookup(h, "dgemm_");
+    if (!L.dsyev || !L.dsteqr || !L.dgees || !L.dtrsyl || !L.dpotrf || !L.dgemm) {
+        dlclose(h);
+        return false;
+    }
+    g_lp = L;
+    return true;
+}
+
+void gemm(char ta, char tb, int m, int n, int k, const double *A, int lda, const double *B, int ldb, double *C, int ldc)
+{
+    const double one = 1.0, zero = 0.0;
+    g_lp.dgemm(&ta, &tb, &m, &n, &k, &one, A, &lda, B, &ldb, &zero, C, &ldc);
+}
+
+} // namespace
+
+extern "C" int rails_host_lapack_init(const char *path)
+{
+    std::lock_guard<std::mutex> lock(g_lp_mutex);
+    if (g_lp.handle) return RAILS_OK;
+    if (path && *path && try_open(path)) return RAILS_OK;
+    if (const char *env = getenv("RAILS_LAPACK_LIB"))
+        if (try_open(env)) return RAILS_OK;
+    // scipy's bundled OpenBLAS (hashed file name): scan the usual site-packages locations
+    static const char *dirs[] = {"/usr/local/lib/python3.10/dist-packages/scipy.libs", "/usr/lib/python3/dist-packages/scipy.libs",
+                                 nullptr};
+    for (int i = 0; dirs[i]; ++i) {
+        std::string cmd = std::string("ls ") + dirs[i] + "/libscipy_openblas*.so 2>/dev/null";
+        if (FILE *f = popen(cmd.c_str(), "r")) {
+            char buf[1024];
+            std::vector<std::string> found;
+            while (fgets(buf, sizeof(buf), f)) {
+                std::string s(buf);
+                while (!s.empty() && (s.back() == '\n' || s.back() == ' ')) s.pop_back();
+                found.push_back(s);
+            }
+            pclose(f);
+            for (auto &s : found)
+                if (try_open(s)) return RAILS_OK;
+        }
+    }
+    static const char *cands[] = {"libopenblas.so.0", "libopenblas.so", "liblapack.so.3", "liblapack.so", "/opt/conda/lib/libmkl_rt.so",
+                                  "libmkl_rt.so", nullptr};
+    for (int i = 0; cands[i]; ++i)
+        if (try_open(cands[i])) return RAILS_OK;
+    rails_set_error("no host LAPACK found: set RAILS_LAPACK_LIB to a library exporting dsyev_/dgees_/dtrsyl_/dpotrf_/dgemm_");
+    return RAILS_ELAPACK;
+}
+
+extern "C" const char *rails_host_lapack_path(void) { return g_lp.path.c_str(); }
+
+extern "C" void rails_dsyev(char jobz, char uplo, int n, double *a, int lda, double *w, int *info)
+{
+    if (rails_host_lapack_init(nullptr) != RAILS_OK) {
+        *info = -100;
+        return;
+    }
+    if (n <= 0) {
+        *info = 0;
+        return;
+    }
+    int lwork = -1;
+    double wq = 0.0;
+    g_lp.dsyev(&jobz, &uplo, &n, a, &lda, w, &wq, &lwork, info); // workspace query, as the reference does
+    if (*info) return;
+    lwork = (int)wq;
+    std::vector<double> work((size_t)std::max(1, lwork));
+    g_lp.dsyev(&jobz, &uplo, &n, a, &lda, w, work.data(), &lwork, info);
+}
+
+extern "C" void rails_dsteqr(char compz, int n, double *d, double *e, double *z, int ldz, double *work, int *info)
+{
+    if (rails_host_lapack_init(nullptr) != RAILS_OK) {
+        *info = -100;
+        return;
+    }
+    g_lp.dsteqr(&compz, &n, d, e, z, &ldz, work, info);
+}
+
+extern "C" void rails_dpotrf(char uplo, int n, double *a, int lda, int *info)
+{
+    if (rails_host_lapack_init(nullptr) != RAILS_OK) {
+        *info = -100;
+        return;
+    }
+    g_lp.dpotrf(&uplo, &n, a, &lda, info);
+}
+
+// Continuous-time Lyapunov equation, SB03MD('C','X','N',trans):
+//   trans = 'T':  A X + X A^T = scale * C        trans = 'N':  A^T X + X A = scale * C
+// C symmetric, X overwrites C.  A is overwritten by its real Schur form (as SLICOT does with FACT='N').
+extern "C" void rails_sb03md(char dico, char job, char fact, char trans, int n, double *A, int lda, double *X, int ldx, double *scale,
+                             int *info)
+{
+    *info = 0;
+    if (n < 1) { // the reference prints "n < 1 is not supported" and returns (src/SlicotWrapper.cpp:12-16)
+        fprintf(stderr, "rails_sb03md: n < 1 is not supported\n");
+        return;
+    }
+    if ((dico != 'C' && dico != 'c') || (job != 'X' && job != 'x') || (fact != 'N' && fact != 'n')) {
+        fprintf(stderr, "rails_sb03md: only DICO='C', JOB='X', FACT='N' is supported\n");
+        *info = -1;
+        return;
+    }
+    if (rails_host_lapack_init(nullptr) != RAILS_OK) {
+        *info = -100;
+        return;
+    }
+    const bool tr = (trans == 'T' || trans == 't' || trans == 'C' || trans == 'c');
+    std::vector<double> U((size_t)n * n), wr(n), wi(n), F((size_t)n * n), W((size_t)n * n);
+    int sdim = 0, lwork = -1, linfo = 0;
+    double wq = 0.0;
+    g_lp.dgees("V", "N", nullptr, &n, A, &lda, &sdim, wr.data(), wi.data(), U.data(), &n, &wq, &lwork, nullptr, &linfo);
+    lwork = std::max((int)wq, 3 * n);
+    std::vector<double> work((size_t)lwork);
+    g_lp.dgees("V", "N", nullptr, &n, A, &lda, &sdim, wr.data(), wi.data(), U.data(), &n, work.data(), &lwork, nullptr, &linfo);
+    if (linfo != 0) { // QR iteration failed: SLICOT reports 0 < info <= n
+        *info = linfo > n ? n : linfo;
+        return;
+    }
+    // F = U^T C U
+    gemm('T', 'N', n, n, n, U.data(), n, X, ldx, W.data(), n);
+    gemm('N', 'N', n, n, n, W.data(), n, U.data(), n, F.data(), n);
+    // S Y + Y S^T = scale F (trans='T')   or   S^T Y + Y S = scale F (trans='N')
+    int isgn = 1, tinfo = 0;
+    g_lp.dtrsyl(tr ? "N" : "T", tr ? "T" : "N", &isgn, &n, &n, A, &lda, A, &lda, F.data(), &n, scale, &tinfo);
+    // X = U Y U^T
+    gemm('N', 'N', n, n, n, U.data(), n, F.data(), n, W.data(), n);
+    gemm('N', 'T', n, n, n, W.data(), n, U.data(), n, F.data(), n);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) X[i + (size_t)j * ldx] = F[i + (size_t)j * n];
+    if (tinfo == 1) *info = n + 1; // perturbed to avoid overflow: A and -A^T have (nearly) common eigenvalues
+}

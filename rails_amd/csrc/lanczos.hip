@@ -1,0 +1,511 @@
+// lanczos.hip -- fused residual Lanczos (src/LyapunovSolver.hpp:367-447) for gfx950.
+//
+// Lanczos on the implicit symmetric operator  R = AV T MV^T + MV T AV^T + B B^T  (MV == V when
+// M = I).  The reference makes 4 passes over the m x k panels per step (V^T q, AV Z, AV^T q, V Z)
+// plus B, alpha, beta and axpy passes.  Here ONE pass over P = [AV MV B] does a whole step:
+//
+//   with c = P^T q_i known (from the previous pass):   g = [T c_MV ; T c_AV ; c_B]
+//        alpha_i = q_i^T R q_i = c_AV.g_AV + c_MV.g_MV + c_B.c_B           (no pass needed)
+//   pass i, per row:   r = P_row . g - alpha_i q_i - beta_{i-1} q_{i-1}     (= un-normalised q_{i+1})
+//                      c' += P_row * r ;  rr += r*r                          (row-local, same pass)
+//   then               beta_i = sqrt(rr),  c_{next} = c' / beta_i.
+//
+// HBM traffic per step = (2k + p + ~4) * m * 8 bytes: the compulsory single read of the panels.
+// The Lanczos vectors live in a column-major side buffer (one contiguous vector per step) so the
+// per-row scalar traffic is coalesced.  alpha, beta and the breakdown test (beta < 1e-14,
+// :419-426) stay on the device; the host reads H back once at the end.
+#include "rails_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+struct rails_lanczos_state {
+    double *Qc = nullptr; // (L+2) vectors of length mpad, column-major
+    size_t qc_bytes = 0;
+    int64_t m = 0, mpad = 0;
+    int steps = 0;
+    int L = 0;
+    double *small = nullptr; // T, coefficients, reduced sums, state, alphas, betas
+    size_t small_bytes = 0;
+};
+
+static rails_lanczos_state g_lz; // one solver per thread at most (reference: not thread-safe either)
+
+namespace {
+
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 64-lane sum, result uniform; fixed association: quads, 8s, 16s by DPP, then the four rows.
+__device__ __forceinline__ double wave_sum(double x)
+{
+    x += dpp_f64<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += dpp_f64<0x4E>(x);  // quad_perm [2,3,0,1]
+    x += dpp_f64<0x141>(x); // row_half_mirror
+    x += dpp_f64<0x140>(x); // row_mirror
+    double s0 = readlane_f64(x, 0), s1 = readlane_f64(x, 16), s2 = readlane_f64(x, 32), s3 = readlane_f64(x, 48);
+    return (s0 + s1) + (s2 + s3);
+}
+
+struct LzArgs {
+    const double *AV;
+    int ldav;
+    const double *MV;
+    int ldmv;
+    const double *B;
+    int ldb;
+    int k, p;
+    int64_t m, mpad;
+    double *Qc;
+    int step;             // -1 = init pass (r := raw q_0)
+    const double *coef;   // [k (for AV) | k (for MV) | p (for B)]
+    const double *state;  // alpha, beta_prev, inv_beta, done, steps
+    double *partial;      // [nblocks][2k+p+1]
+};
+
+// lane l owns column pairs (2(l+64c), 2(l+64c)+1), c < NCH, of AV and of MV, and pair l of B.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_lanczos_pass(LzArgs a)
+{
+    __shared__ double red[4][(4 * NCH + 2) * 64 + 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const bool init = a.step < 0;
+    const double done = a.state[3];
+    const int ncoef = 2 * a.k + a.p + 1;
+    double *myp = a.partial + (int64_t)blockIdx.x * ncoef;
+    if (done != 0.0) {
+        for (int i = threadIdx.x; i < ncoef; i += 256) myp[i] = 0.0;
+        return;
+    }
+    const double alpha = init ? 0.0 : a.state[0];
+    const double betap = init ? 0.0 : a.state[1];
+    const double invb = init ? 1.0 : a.state[2];
+
+    v2f64 gav[NCH], gmv[NCH], gb;
+    bool ok0[NCH], ok1[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        int col = 2 * (lane + 64 * c);
+        ok0[c] = col < a.k;
+        ok1[c] = col + 1 < a.k;
+        gav[c].x = (!init && ok0[c]) ? a.coef[col] : 0.0;
+        gav[c].y = (!init && ok1[c]) ? a.coef[col + 1] : 0.0;
+        gmv[c].x = (!init && ok0[c]) ? a.coef[a.k + col] : 0.0;
+        gmv[c].y = (!init && ok1[c]) ? a.coef[a.k + col + 1] : 0.0;
+    }
+    const bool bok0 = 2 * lane < a.p, bok1 = 2 * lane + 1 < a.p;
+    gb.x = (!init && bok0) ? a.coef[2 * a.k + 2 * lane] : 0.0;
+    gb.y = (!init && bok1) ? a.coef[2 * a.k + 2 * lane + 1] : 0.0;
+
+    v2f64 cav[NCH], cmv[NCH], cb;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        cav[c] = (v2f64){0.0, 0.0};
+        cmv[c] = (v2f64){0.0, 0.0};
+    }
+    cb = (v2f64){0.0, 0.0};
+    double rr = 0.0;
+
+    double *q_cur = a.Qc + (int64_t)(init ? 0 : a.step) * a.mpad;
+    const double *q_prev = a.Qc + (int64_t)((init || a.step == 0) ? 0 : a.step - 1) * a.mpad;
+    double *q_next = a.Qc + (int64_t)(a.step + 1) * a.mpad;
+    const bool have_prev = (!init && a.step > 0);
+
+    const int64_t ngroups = a.mpad / 64;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = grp * 64;
+        double qn = q_cur[row0 + lane] * invb; // rows >= m hold zeros
+        double qm = have_prev ? q_prev[row0 + lane] : 0.0;
+        if (!init) q_cur[row0 + lane] = qn; // store the normalised q_i
+        double rvec = 0.0;
+        const int nrows = (int)((a.m - row0) < 64 ? (a.m - row0) : 64);
+        for (int j = 0; j < nrows; ++j) {
+            const int64_t row = row0 + j;
+            v2f64 xav[NCH], xmv[NCH], xb;
+            const double *pav = a.AV + row * a.ldav + 2 * lane;
+            const double *pmv = a.MV + row * a.ldmv + 2 * lane;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                xav[c] = (v2f64){0.0, 0.0};
+                xmv[c] = (v2f64){0.0, 0.0};
+                if (ok0[c]) {
+                    xav[c] = *reinterpret_cast<const v2f64 *>(pav + 128 * c);
+                    xmv[c] = *reinterpret_cast<const v2f64 *>(pmv + 128 * c);
+                    if (!ok1[c]) {
+                        xav[c].y = 0.0;
+                        xmv[c].y = 0.0;
+                    }
+                }
+            }
+            xb = (v2f64){0.0, 0.0};
+            if (bok0) {
+                xb = *reinterpret_cast<const v2f64 *>(a.B + row * a.ldb + 2 * lane);
+                if (!bok1) xb.y = 0.0;
+            }
+            double r;
+            const double qi = readlane_f64(qn, j);
+            if (init) {
+                r = qi;
+            } else {
+                double t = 0.0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    t = __builtin_fma(xav[c].x, gav[c].x, t);
+                    t = __builtin_fma(xav[c].y, gav[c].y, t);
+                    t = __builtin_fma(xmv[c].x, gmv[c].x, t);
+                    t = __builtin_fma(xmv[c].y, gmv[c].y, t);
+                }
+                t = __builtin_fma(xb.x, gb.x, t);
+                t = __builtin_fma(xb.y, gb.y, t);
+                const double total = wave_sum(t);
+                const double qmi = readlane_f64(qm, j);
+                r = total - alpha * qi - betap * qmi;
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                cav[c].x = __builtin_fma(xav[c].x, r, cav[c].x);
+                cav[c].y = __builtin_fma(xav[c].y, r, cav[c].y);
+                cmv[c].x = __builtin_fma(xmv[c].x, r, cmv[c].x);
+                cmv[c].y = __builtin_fma(xmv[c].y, r, cmv[c].y);
+            }
+            cb.x = __builtin_fma(xb.x, r, cb.x);
+            cb.y = __builtin_fma(xb.y, r, cb.y);
+            rr = __builtin_fma(r, r, rr);
+            rvec = (lane == j) ? r : rvec;
+        }
+        if (!init) q_next[row0 + lane] = rvec;
+    }
+
+    // block reduction in a fixed order: wave 0 += wave 1, 2, 3
+    double *mine = red[wave];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        mine[(4 * c + 0) * 64 + lane] = cav[c].x;
+        mine[(4 * c + 1) * 64 + lane] = cav[c].y;
+        mine[(4 * c + 2) * 64 + lane] = cmv[c].x;
+        mine[(4 * c + 3) * 64 + lane] = cmv[c].y;
+    }
+    mine[(4 * NCH + 0) * 64 + lane] = cb.x;
+    mine[(4 * NCH + 1) * 64 + lane] = cb.y;
+    if (lane == 0) mine[(4 * NCH + 2) * 64] = rr;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int slot = (4 * c + e) * 64 + lane;
+                double s = ((red[0][slot] + red[1][slot]) + red[2][slot]) + red[3][slot];
+                int col = 2 * (lane + 64 * c) + (e & 1);
+                if (col < a.k) myp[(e < 2 ? 0 : a.k) + col] = s;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int slot = (4 * NCH + e) * 64 + lane;
+            double s = ((red[0][slot] + red[1][slot]) + red[2][slot]) + red[3][slot];
+            int col = 2 * lane + e;
+            if (col < a.p) myp[2 * a.k + col] = s;
+        }
+        if (lane == 0) {
+            int slot = (4 * NCH + 2) * 64;
+            myp[2 * a.k + a.p] = ((red[0][slot] + red[1][slot]) + red[2][slot]) + red[3][slot];
+        }
+    }
+}
+
+__global__ void k_lz_reduce(const double *__restrict__ partial, int nblocks, int n, double *__restrict__ out)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int t = 0; t < nblocks; ++t) s += partial[(int64_t)t * n + e];
+    out[e] = s;
+}
+
+// One block.  sums = [c'_AV (k) | c'_MV (k) | c'_B (p) | rr] (already all-reduced).
+// Writes the coefficients for the next pass, alpha/beta bookkeeping and the breakdown flag.
+__global__ __launch_bounds__(256) void k_lz_small(const double *__restrict__ sums, const double *__restrict__ T, int k, int p, int step,
+                                                  double *__restrict__ coef, double *__restrict__ state, double *__restrict__ alphas,
+                                                  double *__restrict__ betas)
+{
+    __shared__ double sh[256];
+    if (state[3] != 0.0) return;
+    const int tid = threadIdx.x;
+    const double rr = sums[2 * k + p];
+    const double beta = sqrt(rr);
+    const bool init = step < 0;
+    if (!init && beta < 1e-14) { // src/LyapunovSolver.hpp:419-426
+        if (tid == 0) {
+            betas[step] = beta;
+            state[3] = 1.0;
+            state[4] = (double)(step + 1);
+        }
+        return;
+    }
+    const double inv = 1.0 / beta;
+    // g_AV = T (c_MV * inv),  g_MV = T (c_AV * inv),  g_B = c_B * inv
+    for (int j = tid; j < k; j += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int l = 0; l < k; ++l) {
+            double t = T[j + (int64_t)l * k];
+            s1 = __builtin_fma(t, sums[k + l] * inv, s1);
+            s2 = __builtin_fma(t, sums[l] * inv, s2);
+        }
+        coef[j] = s1;
+        coef[k + j] = s2;
+    }
+    for (int j = tid; j < p; j += 256) coef[2 * k + j] = sums[2 * k + j] * inv;
+    __syncthreads();
+    // alpha_next = c_AV.g_AV + c_MV.g_MV + c_B.c_B
+    double part = 0.0;
+    for (int j = tid; j < k; j += 256) {
+        part = __builtin_fma(sums[j] * inv, coef[j], part);
+        part = __builtin_fma(sums[k + j] * inv, coef[k + j], part);
+    }
+    for (int j = tid; j < p; j += 256) {
+        double cbv = sums[2 * k + j] * inv;
+        part = __builtin_fma(cbv, cbv, part);
+    }
+    sh[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double alpha_next = sh[0];
+        state[0] = alpha_next;
+        state[1] = init ? 0.0 : beta;
+        state[2] = inv;
+        alphas[step + 1] = alpha_next;
+        if (!init) {
+            betas[step] = beta;
+            state[4] = (double)(step + 1);
+        }
+    }
+}
+
+// Out[row, oc0 + j] = sum_l Qc[l][row] * S[l + j*lds],  j < w (<= 16 per launch chunk)
+__global__ __launch_bounds__(256) void k_lz_vectors(const double *__restrict__ Qc, int64_t mpad, int64_t m, int steps,
+                                                    const double *__restrict__ S, int lds, int w, double *__restrict__ Out, int ldo)
+{
+    extern __shared__ double Ss[]; // steps x 16
+    for (int idx = threadIdx.x; idx < steps * 16; idx += blockDim.x) {
+        int l = idx / 16, j = idx % 16;
+        Ss[idx] = (j < w) ? S[l + (int64_t)j * lds] : 0.0;
+    }
+    __syncthreads();
+    int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= m) return;
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+    for (int l = 0; l < steps; ++l) {
+        double q = Qc[(int64_t)l * mpad + row];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = __builtin_fma(q, Ss[l * 16 + j], acc[j]);
+    }
+    double *o = Out + row * ldo;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < w) o[j] = acc[j];
+}
+
+__global__ void k_lz_random(double *__restrict__ q, int64_t m, int64_t mpad, uint64_t seed, uint64_t stream, int64_t row0);
+
+__device__ __forceinline__ uint64_t sm64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void k_lz_random(double *__restrict__ q, int64_t m, int64_t mpad, uint64_t seed, uint64_t stream, int64_t row0)
+{
+    uint64_t hs = sm64(seed ^ sm64(stream * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull));
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < mpad; r += (int64_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (r < m) {
+            uint64_t h = sm64(hs ^ sm64((uint64_t)(row0 + r) * 0x9E3779B97F4A7C15ull + 1));
+            double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+            v = 2.0 * u - 1.0;
+        }
+        q[r] = v;
+    }
+}
+
+template <int NCH>
+void launch_pass(rails_ctx *c, const LzArgs &a, int nblocks)
+{
+    hipLaunchKernelGGL((k_lanczos_pass<NCH>), dim3(nblocks), dim3(256), 0, c->stream, a);
+}
+
+} // namespace
+
+extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0, const rails_panel *MV, int mvc0, int k,
+                                   const double *T_host, int ldt, const rails_panel *B, int bc0, int p, int L, double *H_host,
+                                   int ldh, int *steps_out)
+{
+    RAILS_REQUIRE(c && AV && MV && B && H_host && steps_out, "rails_resid_lanczos: null argument");
+    RAILS_REQUIRE(k >= 0 && p >= 0 && L >= 1 && ldh >= L + 1, "rails_resid_lanczos: bad sizes k=%d p=%d L=%d ldh=%d", k, p, L, ldh);
+    RAILS_REQUIRE(avc0 >= 0 && avc0 + k <= AV->cap && mvc0 >= 0 && mvc0 + k <= MV->cap && bc0 >= 0 && bc0 + p <= B->cap,
+                  "rails_resid_lanczos: column windows outside capacity");
+    RAILS_REQUIRE(AV->m == MV->m && AV->m == B->m, "rails_resid_lanczos: row mismatch");
+    RAILS_REQUIRE(((avc0 | mvc0 | bc0) & 1) == 0, "rails_resid_lanczos: column windows must start at even columns");
+    RAILS_REQUIRE(k <= 512 && p <= 128, "rails_resid_lanczos: fused kernel supports k <= 512, p <= 128 (got %d, %d)", k, p);
+    RAILS_REQUIRE(k == 0 || (T_host && ldt >= k), "rails_resid_lanczos: bad T");
+    const int64_t m = AV->m;
+    const int64_t mpad = (m + 63) / 64 * 64;
+    rails_lanczos_state &S = g_lz;
+    // Lanczos vectors
+    size_t qbytes = (size_t)(L + 2) * (size_t)std::max<int64_t>(mpad, 64) * sizeof(double);
+    if (qbytes > S.qc_bytes) {
+        RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (S.Qc) RAILS_HIP_CHECK(hipFree(S.Qc));
+        S.Qc = nullptr;
+        S.qc_bytes = 0;
+        hipError_t e = hipMalloc((void **)&S.Qc, qbytes);
+        if (e != hipSuccess) {
+            rails_set_error("rails_resid_lanczos: hipMalloc(%zu) failed: %s", qbytes, hipGetErrorString(e));
+            return RAILS_ENOMEM;
+        }
+        S.qc_bytes = qbytes;
+    }
+    S.m = m;
+    S.mpad = std::max<int64_t>(mpad, 64);
+    S.L = L;
+    S.steps = 0;
+    const int ncoef = 2 * k + p + 1;
+    int64_t ngroups = S.mpad / 64;
+    int nblocks = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)c->num_cu * 4);
+    if (nblocks < 1) nblocks = 1;
+    // small device block: T | coef | sums | state(8) | alphas(L+2) | betas(L+2)
+    size_t nsmall = (size_t)k * k + ncoef + ncoef + 8 + 2 * (size_t)(L + 2);
+    if (nsmall * sizeof(double) > S.small_bytes) {
+        RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (S.small) RAILS_HIP_CHECK(hipFree(S.small));
+        S.small = nullptr;
+        RAILS_HIP_CHECK(hipMalloc((void **)&S.small, nsmall * sizeof(double) * 2));
+        S.small_bytes = nsmall * sizeof(double) * 2;
+    }
+    double *dT = S.small;
+    double *dcoef = dT + (size_t)k * k;
+    double *dsums = dcoef + ncoef;
+    double *dstate = dsums + ncoef;
+    double *dalpha = dstate + 8;
+    double *dbeta = dalpha + (L + 2);
+    RAILS_TRY(rails_ws_reserve(c, (size_t)nblocks * ncoef * sizeof(double)));
+    RAILS_TRY(rails_pinned_reserve(c, std::max<size_t>((size_t)k * k, (size_t)(2 * (L + 2) + 8)) * sizeof(double)));
+    // T -> device (contiguous k x k)
+    for (int j = 0; j < k; ++j) memcpy(c->pinned + (size_t)j * k, T_host + (size_t)j * ldt, sizeof(double) * k);
+    if (k) RAILS_HIP_CHECK(hipMemcpyAsync(dT, c->pinned, (size_t)k * k * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RAILS_HIP_CHECK(hipMemsetAsync(dcoef, 0, (nsmall - (size_t)k * k) * sizeof(double), c->stream));
+    // start vector: Q.random() consumes one RNG stream (src/LyapunovSolver.hpp:374)
+    {
+        uint64_t stream = c->next_stream++;
+        int grid = (int)std::min<int64_t>((S.mpad + 255) / 256, (int64_t)c->num_cu * 8);
+        hipLaunchKernelGGL(k_lz_random, dim3(grid), dim3(256), 0, c->stream, S.Qc, m, S.mpad, c->seed, stream, c->row0);
+    }
+    LzArgs a;
+    a.AV = AV->d + avc0;
+    a.ldav = AV->ld;
+    a.MV = MV->d + mvc0;
+    a.ldmv = MV->ld;
+    a.B = B->d + bc0;
+    a.ldb = B->ld;
+    a.k = k;
+    a.p = p;
+    a.m = m;
+    a.mpad = S.mpad;
+    a.Qc = S.Qc;
+    a.coef = dcoef;
+    a.state = dstate;
+    a.partial = c->ws;
+    const int nch = std::max(1, (k + 127) / 128);
+    for (int step = -1; step < L; ++step) {
+        a.step = step;
+        switch (nch) {
+        case 1: launch_pass<1>(c, a, nblocks); break;
+        case 2: launch_pass<2>(c, a, nblocks); break;
+        case 3: launch_pass<3>(c, a, nblocks); break;
+        default: launch_pass<4>(c, a, nblocks); break;
+        }
+        hipLaunchKernelGGL(k_lz_reduce, dim3((ncoef + 255) / 256), dim3(256), 0, c->stream, c->ws, nblocks, ncoef, dsums);
+        RAILS_TRY(rails_allreduce_dev(c, dsums, (size_t)ncoef));
+        hipLaunchKernelGGL(k_lz_small, dim3(1), dim3(256), 0, c->stream, dsums, dT, k, p, step, dcoef, dstate, dalpha, dbeta);
+    }
+    RAILS_HIP_CHECK(hipGetLastError());
+    // read back state, alphas, betas (contiguous)
+    size_t nback = 8 + 2 * (size_t)(L + 2);
+    RAILS_HIP_CHECK(hipMemcpyAsync(c->pinned, dstate, nback * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const double *hstate = c->pinned, *halpha = c->pinned + 8, *hbeta = halpha + (L + 2);
+    const bool broke = hstate[3] != 0.0;
+    int steps = broke ? (int)hstate[4] : L;
+    for (int j = 0; j <= L; ++j)
+        for (int i = 0; i <= L; ++i) H_host[i + (size_t)j * ldh] = 0.0; // H = 0.0 (:377)
+    for (int i = 0; i < steps; ++i) {
+        H_host[i + (size_t)i * ldh] = halpha[i]; // :407
+        bool last_broke = broke && (i == steps - 1);
+        if (!last_broke) { // :428-429
+            H_host[(i + 1) + (size_t)i * ldh] = hbeta[i];
+            H_host[i + (size_t)(i + 1) * ldh] = hbeta[i];
+        }
+    }
+    S.steps = steps;
+    *steps_out = steps;
+    return RAILS_OK;
+}
+
+extern "C" int rails_lanczos_vectors(rails_ctx *c, const double *S_host, int lds, int w, rails_panel *Out, int oc0)
+{
+    rails_lanczos_state &S = g_lz;
+    RAILS_REQUIRE(c && Out, "rails_lanczos_vectors: null argument");
+    RAILS_REQUIRE(S.Qc && S.steps > 0, "rails_lanczos_vectors: no Lanczos run to take vectors from");
+    RAILS_REQUIRE(w >= 0 && oc0 >= 0 && oc0 + w <= Out->cap, "rails_lanczos_vectors: columns [%d,%d) outside capacity %d", oc0, oc0 + w,
+                  Out->cap);
+    RAILS_REQUIRE(Out->m == S.m, "rails_lanczos_vectors: row mismatch %lld vs %lld", (long long)Out->m, (long long)S.m);
+    RAILS_REQUIRE(w == 0 || (S_host && lds >= S.steps), "rails_lanczos_vectors: bad coefficient matrix");
+    if (w == 0 || S.m == 0) return RAILS_OK;
+    const int steps = S.steps;
+    size_t n = (size_t)steps * w;
+    RAILS_TRY(rails_small_reserve(c, n * sizeof(double)));
+    RAILS_TRY(rails_pinned_reserve(c, n * sizeof(double)));
+    for (int j = 0; j < w; ++j) memcpy(c->pinned + (size_t)j * steps, S_host + (size_t)j * lds, sizeof(double) * steps);
+    RAILS_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    for (int j0 = 0; j0 < w; j0 += 16) {
+        int wc = std::min(16, w - j0);
+        hipLaunchKernelGGL(k_lz_vectors, dim3((unsigned)((S.m + 255) / 256)), dim3(256), (size_t)steps * 16 * sizeof(double), c->stream,
+                           S.Qc, S.mpad, S.m, steps, c->small + (size_t)j0 * steps, steps, wc, Out->d + oc0 + j0, Out->ld);
+    }
+    RAILS_HIP_CHECK(hipGetLastError());
+    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RAILS_OK;
+}
+
+extern "C" int rails_lanczos_release(void)
+{
+    rails_lanczos_state &S = g_lz;
+    if (S.Qc) hipFree(S.Qc);
+    if (S.small) hipFree(S.small);
+    S = rails_lanczos_state();
+    return RAILS_OK;
+}

@@ -1,0 +1,144 @@
+// orth.hip -- orthonormalisation of newly appended panel columns.
+//
+// Reference: StlWrapper::orthogonalize (src/StlWrapper.cpp:305-321): for every column past the
+// watermark, normalise, twice subtract the projection on ALL previous columns, normalise -- four
+// passes over the m x k panel per new column.
+//
+// Here (auto / block method): the w new columns W are treated as a block,
+//     twice:  C = V_old^T W  (MFMA Gram, one all-reduce);  W -= V_old C  (MFMA panel GEMM)
+//     twice:  G = W^T W;  G = R^T R (host Cholesky, w x w);  W <- W R^-1          (CholQR2)
+// which is two Gram and two update passes for all w columns together.  Gram-Schmidt on the columns
+// of W in order and the Cholesky factor of W^T W produce the same Q (QR with positive diagonal is
+// unique), so the result equals the reference's up to rounding.  When the block Gram matrix is
+// numerically rank deficient (Cholesky fails or its diagonal collapses) the routine falls back to
+// the reference's column-wise recurrence, evaluated with the same device kernels.
+#include "rails_internal.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+int sync_small_to_host(rails_ctx *c, size_t n, std::vector<double> &out)
+{
+    RAILS_TRY(rails_pinned_reserve(c, n * sizeof(double)));
+    RAILS_HIP_CHECK(hipMemcpyAsync(c->pinned, c->small, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    out.assign(c->pinned, c->pinned + n);
+    return RAILS_OK;
+}
+
+int upload_small(rails_ctx *c, const std::vector<double> &in, double *dst)
+{
+    RAILS_TRY(rails_pinned_reserve(c, in.size() * sizeof(double)));
+    memcpy(c->pinned, in.data(), in.size() * sizeof(double));
+    RAILS_HIP_CHECK(hipMemcpyAsync(dst, c->pinned, in.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RAILS_OK;
+}
+
+// 2-norm of one column = sqrt(|v^T v|) (StlWrapper::norm on a single column, src/StlWrapper.cpp:280-288)
+int column_norm(rails_ctx *c, const rails_panel *V, int col, double *nrm)
+{
+    RAILS_TRY(rails_small_reserve(c, sizeof(double)));
+    RAILS_TRY(rails_gram_dev(c, V->d + col, V->ld, V->d + col, V->ld, V->m, 1, 1, c->small));
+    RAILS_TRY(rails_allreduce_dev(c, c->small, 1));
+    std::vector<double> h;
+    RAILS_TRY(sync_small_to_host(c, 1, h));
+    *nrm = std::sqrt(std::fabs(h[0]));
+    return RAILS_OK;
+}
+
+int columnwise(rails_ctx *c, rails_panel *V, int from, int to)
+{
+    for (int i = from; i < to; ++i) {
+        double nrm = 0.0;
+        RAILS_TRY(column_norm(c, V, i, &nrm));
+        RAILS_TRY(rails_panel_scale(c, V, i, 1, 1.0 / nrm));
+        if (i) {
+            RAILS_TRY(rails_small_reserve(c, (size_t)i * sizeof(double)));
+            for (int pass = 0; pass < 2; ++pass) {
+                RAILS_TRY(rails_gram_dev(c, V->d, V->ld, V->d + i, V->ld, V->m, i, 1, c->small));
+                RAILS_TRY(rails_allreduce_dev(c, c->small, (size_t)i));
+                RAILS_TRY(rails_panel_gemm_dev(c, -1.0, V->d, V->ld, i, c->small, 1, 1.0, V->d + i, V->ld, V->m));
+            }
+        }
+        RAILS_TRY(column_norm(c, V, i, &nrm));
+        RAILS_TRY(rails_panel_scale(c, V, i, 1, 1.0 / nrm));
+    }
+    return RAILS_OK;
+}
+
+} // namespace
+
+extern "C" int rails_orthogonalize(rails_ctx *c, rails_panel *V, int k_old, int w, int method, int *used)
+{
+    RAILS_REQUIRE(c && V, "rails_orthogonalize: null argument");
+    RAILS_REQUIRE(k_old >= 0 && w >= 0 && k_old + w <= V->cap, "rails_orthogonalize: columns [%d,%d) outside capacity %d", k_old,
+                  k_old + w, V->cap);
+    RAILS_REQUIRE(method >= 0 && method <= 2, "rails_orthogonalize: bad method %d", method);
+    if (used) *used = 0;
+    if (w == 0) return RAILS_OK;
+    if (method == 1 || w > 256) {
+        if (used) *used = 1;
+        return columnwise(c, V, k_old, k_old + w);
+    }
+    double *W = V->d + k_old;
+    // block CGS2 against the old columns
+    if (k_old > 0) {
+        RAILS_TRY(rails_small_reserve(c, (size_t)k_old * w * sizeof(double)));
+        for (int pass = 0; pass < 2; ++pass) {
+            RAILS_TRY(rails_gram_dev(c, V->d, V->ld, W, V->ld, V->m, k_old, w, c->small));
+            RAILS_TRY(rails_allreduce_dev(c, c->small, (size_t)k_old * w));
+            for (int j0 = 0; j0 < w; j0 += 256) { // panel GEMM handles <= 256 output columns per launch
+                int wc = w - j0 < 256 ? w - j0 : 256;
+                RAILS_TRY(rails_panel_gemm_dev(c, -1.0, V->d, V->ld, k_old, c->small + (size_t)j0 * k_old, wc, 1.0, W + j0, V->ld, V->m));
+            }
+        }
+    }
+    // CholQR2 inside the block
+    RAILS_TRY(rails_small_reserve(c, (size_t)w * w * sizeof(double)));
+    for (int pass = 0; pass < 2; ++pass) {
+        RAILS_TRY(rails_gram_dev(c, W, V->ld, W, V->ld, V->m, w, w, c->small));
+        RAILS_TRY(rails_allreduce_dev(c, c->small, (size_t)w * w));
+        std::vector<double> G;
+        RAILS_TRY(sync_small_to_host(c, (size_t)w * w, G));
+        double dmax = 0.0;
+        for (int i = 0; i < w; ++i) dmax = std::max(dmax, G[i + (size_t)i * w]);
+        std::vector<double> R = G;
+        int info = 0;
+        rails_dpotrf('U', w, R.data(), w, &info);
+        bool bad = (info != 0) || !(dmax > 0.0);
+        if (!bad) {
+            // a diagonal of R much smaller than the column norm means the column lies (numerically)
+            // in the span of the others: CholQR would amplify rounding by (norm/r_ii)^2
+            for (int i = 0; i < w; ++i) {
+                double rii = R[i + (size_t)i * w];
+                double nrm = std::sqrt(G[i + (size_t)i * w]);
+                if (!(rii > 1e-5 * nrm)) bad = true;
+            }
+        }
+        if (bad) {
+            if (method == 2) {
+                rails_set_error("rails_orthogonalize: block Gram matrix is rank deficient (dpotrf info %d)", info);
+                return RAILS_ELAPACK;
+            }
+            if (used) *used = 1;
+            return columnwise(c, V, k_old, k_old + w);
+        }
+        // Rinv (upper triangular): solve R * Rinv = I column by column
+        std::vector<double> Rinv((size_t)w * w, 0.0);
+        for (int j = 0; j < w; ++j) {
+            Rinv[j + (size_t)j * w] = 1.0 / R[j + (size_t)j * w];
+            for (int i = j - 1; i >= 0; --i) {
+                double s = 0.0;
+                for (int l = i + 1; l <= j; ++l) s += R[i + (size_t)l * w] * Rinv[l + (size_t)j * w];
+                Rinv[i + (size_t)j * w] = -s / R[i + (size_t)i * w];
+            }
+        }
+        RAILS_TRY(upload_small(c, Rinv, c->small));
+        RAILS_TRY(rails_panel_gemm_dev(c, 1.0, W, V->ld, w, c->small, w, 0.0, W, V->ld, V->m)); // in place, row-local
+    }
+    if (used) *used = 2;
+    return RAILS_OK;
+}

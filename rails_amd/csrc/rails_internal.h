@@ -1,0 +1,125 @@
+// Internal declarations shared by the HIP translation units of librails_hip.so.
+#ifndef RAILS_INTERNAL_H
+#define RAILS_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rails_hip.h"
+
+void rails_set_error(const char *fmt, ...);
+
+#define RAILS_HIP_CHECK(expr)                                                                      \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            rails_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return RAILS_EHIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+#define RAILS_REQUIRE(cond, ...)                                                                   \
+    do {                                                                                           \
+        if (!(cond)) {                                                                             \
+            rails_set_error(__VA_ARGS__);                                                          \
+            return RAILS_EINVAL;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+#define RAILS_TRY(expr)                                                                            \
+    do {                                                                                           \
+        int rc__ = (expr);                                                                         \
+        if (rc__ != RAILS_OK) return rc__;                                                         \
+    } while (0)
+
+// pad the leading dimension to a multiple of 16 doubles (128 B): every row starts on a cache line
+static inline int rails_pad_ld(int capacity) { return ((capacity < 1 ? 1 : capacity) + 15) / 16 * 16; }
+
+struct rails_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    // RNG
+    uint64_t seed = 1;
+    uint64_t next_stream = 0;
+    // partition
+    int rank = 0, nranks = 1;
+    int64_t row0 = 0, m_global = -1;
+    rails_allreduce_fn allreduce = nullptr;
+    void *allreduce_user = nullptr;
+    // device workspace for reduction partials / small matrices
+    double *ws = nullptr;
+    size_t ws_bytes = 0;
+    // second device scratch (small matrices uploaded per call)
+    double *small = nullptr;
+    size_t small_bytes = 0;
+    // pinned host staging
+    double *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct rails_panel {
+    rails_ctx *ctx = nullptr;
+    double *d = nullptr;
+    int64_t m = 0; // local rows (+ ghost rows for operator inputs are held separately)
+    int cap = 0;
+    int ld = 0;
+};
+
+struct rails_csr {
+    rails_ctx *ctx = nullptr;
+    int64_t m = 0, ncols_ext = 0, nnz = 0;
+    int64_t *rowptr = nullptr;
+    int32_t *col = nullptr;
+    double *val = nullptr;
+    int max_row_nnz = 0;
+    // transposed copy, built lazily
+    rails_csr *AT = nullptr;
+    // host copy kept for building the transpose / tiling analysis
+    std::vector<int64_t> h_rowptr;
+    std::vector<int32_t> h_col;
+    std::vector<double> h_val;
+    // halo
+    int64_t n_send = 0, n_ghost = 0;
+    int64_t *send_rows = nullptr;
+    double *send_buf = nullptr;
+    double *ext = nullptr; // [m + n_ghost] x ld_ext staging of X with ghosts appended
+    size_t send_cap = 0, ext_cap = 0;
+    rails_halo_fn halo = nullptr;
+    void *halo_user = nullptr;
+    // LDS-staged footprint kernel (spmm.hip): per row-block column footprints
+    int variant = 0;
+    bool tiled_ready = false;
+    bool tiled_ok = false;
+    int tile_rows = 0;
+    int64_t n_tiles = 0;
+    int32_t *t_fp_ptr = nullptr; // [n_tiles+1] offsets into t_fp
+    int32_t *t_fp = nullptr;     // footprint column lists
+    uint16_t *t_lcol = nullptr;  // [nnz] local (footprint-relative) column of every nonzero
+    int max_fp = 0;
+    const char *last_kernel = "";
+};
+
+// ---- helpers implemented in ctx.hip ----
+int rails_ws_reserve(rails_ctx *ctx, size_t bytes);
+int rails_small_reserve(rails_ctx *ctx, size_t bytes);
+int rails_pinned_reserve(rails_ctx *ctx, size_t bytes);
+int rails_allreduce_dev(rails_ctx *ctx, double *dev, size_t n);
+
+// ---- kernels / launchers across translation units ----
+// dense.hip: partial Gram into device memory (no host copy / all-reduce): C_dev (a x b col-major, ldc = a)
+int rails_gram_dev(rails_ctx *ctx, const double *X, int ldx, const double *Y, int ldy, int64_t m, int a, int b,
+                   double *C_dev);
+int rails_panel_gemm_dev(rails_ctx *ctx, double alpha, const double *X, int ldx, int k, const double *C_dev,
+                         int r, double beta, double *Y, int ldy, int64_t m);
+
+#endif

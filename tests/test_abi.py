@@ -1,0 +1,106 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol the public headers declare
+(no device compute is attempted here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(rails_[a-z0-9_]+)\s*\(", text))
+    typedefs = set(re.findall(r"\(\*\s*(rails_[a-z0-9_]+)\s*\)", text))
+    return sorted(names - typedefs)
+
+
+def test_library_exports_every_declared_symbol():
+    import rails_amd
+
+    lib = rails_amd.load()
+    headers = [h for h in os.listdir(os.path.join(ROOT, "include")) if h.endswith(".h")]
+    assert "rails_hip.h" in headers
+    missing = []
+    for h in headers:
+        for name in _declared(h):
+            if not hasattr(lib, name):
+                missing.append((h, name))
+    assert not missing, missing
+    assert b"gfx950" in lib.rails_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a host without a gfx950 device the context creation must fail loudly, not fall back."""
+    import torch
+
+    import rails_amd
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(rails_amd.RailsError):
+        rails_amd.Context(device=0)
+
+
+def test_host_sb03md_kats():
+    # test/SlicotWrapper_test.cpp:7-38 through the product's host C ABI
+    import rails_amd
+
+    lib = rails_amd.load()
+    dp = C.POINTER(C.c_double)
+    A = np.array([[2.0]], order="F")
+    X = np.array([[-4.0]], order="F")
+    scale, info = C.c_double(1.0), C.c_int(0)
+    lib.rails_sb03md(b"C", b"X", b"N", b"T", 1, A.ctypes.data_as(dp), 1, X.ctypes.data_as(dp), 1, C.byref(scale), C.byref(info))
+    assert X[0, 0] == -1.0 and info.value == 0
+    A = np.array([[0.0, 1.0], [-5.0, -5.0]], order="F")
+    X = np.array([[-1.0, 0.0], [0.0, -1.0]], order="F")
+    lib.rails_sb03md(b"C", b"X", b"N", b"T", 2, A.ctypes.data_as(dp), 2, X.ctypes.data_as(dp), 2, C.byref(scale), C.byref(info))
+    np.testing.assert_allclose(X, [[0.62, -0.5], [-0.5, 0.6]], rtol=0, atol=1e-14)
+    assert info.value == 0 and scale.value == 1.0
+
+
+def test_host_sb03md_matches_oracle(oracle):
+    import rails_amd
+
+    lib = rails_amd.load()
+    dp = C.POINTER(C.c_double)
+    g = np.random.default_rng(0)
+    for n in (3, 17, 64):
+        A = g.uniform(-1, 1, (n, n)) - 4 * np.eye(n)
+        Cm = g.uniform(-1, 1, (n, n))
+        Cm = Cm + Cm.T
+        Xo, sc, info = oracle.sb03md(A, Cm)
+        Ap, Xp = np.asfortranarray(A.copy()), np.asfortranarray(Cm.copy())
+        scale, inf = C.c_double(1.0), C.c_int(0)
+        lib.rails_sb03md(b"C", b"X", b"N", b"T", n, Ap.ctypes.data_as(dp), n, Xp.ctypes.data_as(dp), n, C.byref(scale), C.byref(inf))
+        assert inf.value == 0
+        np.testing.assert_allclose(Xp, Xo, atol=1e-12)
+        assert np.abs(A @ Xp + Xp @ A.T - scale.value * Cm).max() < 1e-12
+
+
+def test_host_dsyev_and_dsteqr():
+    import rails_amd
+
+    lib = rails_amd.load()
+    dp = C.POINTER(C.c_double)
+    # test/GenericDenseMatrixWrapper_test.cpp eig KAT shape: symmetric tridiagonal, ascending eigenvalues
+    n = 6
+    d = np.arange(1.0, n + 1)
+    e = np.full(n - 1, 0.5)
+    S = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    a = np.asfortranarray(S.copy())
+    w = np.zeros(n)
+    info = C.c_int(0)
+    lib.rails_dsyev(b"V", b"U", n, a.ctypes.data_as(dp), n, w.ctypes.data_as(dp), C.byref(info))
+    assert info.value == 0
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(S), atol=1e-13)
+    np.testing.assert_allclose(a @ np.diag(w) @ a.T, S, atol=1e-13)
+    z = np.asfortranarray(np.eye(n))
+    dd, ee, work = d.copy(), e.copy(), np.zeros(2 * n)
+    lib.rails_dsteqr(b"I", n, dd.ctypes.data_as(dp), ee.ctypes.data_as(dp), z.ctypes.data_as(dp), n, work.ctypes.data_as(dp), C.byref(info))
+    assert info.value == 0
+    np.testing.assert_allclose(dd, w, atol=1e-13)

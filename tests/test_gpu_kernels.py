@@ -1,0 +1,310 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle on identical inputs.
+
+fp64 tolerances (stated per test): integer/index work is exact; SpMM <= 1e-14*sqrt(nnz/row) relative;
+row reductions (Gram, Lanczos sums) differ from the oracle only by summation order:
+<= 1e-13 * sqrt(m)-scaled bounds.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import rails_amd
+
+    c = rails_amd.Context(device=0, seed=1234)
+    yield c
+    c.close()
+
+
+def MV(ctx, data=None, **kw):
+    import rails_amd
+
+    return rails_amd.HipMultiVectorWrapper(ctx, data=data, **kw)
+
+
+def test_transfer_and_blas1(ctx):
+    g = np.random.default_rng(0)
+    for m, n in ((1, 1), (5, 3), (257, 17), (4099, 40)):
+        X = g.uniform(-1, 1, (m, n))
+        a = MV(ctx, X, capacity=n + 7)
+        assert np.array_equal(a.to_host(), X)
+        b = a.copy()
+        b *= 2.5
+        assert np.array_equal(b.to_host(), X * 2.5)
+        b += a
+        np.testing.assert_array_equal(b.to_host(), X * 2.5 + X)
+        b -= a
+        b /= 13.0
+        np.testing.assert_array_equal(b.to_host(), (X * 2.5 + X - X) * (1.0 / 13.0))
+        # views write through, also at odd column offsets
+        if n >= 3:
+            v = a.view(1, 2)
+            v.assign(7.0)
+            Xe = X.copy()
+            Xe[:, 1:3] = 7.0
+            assert np.array_equal(a.to_host(), Xe)
+        a.resize(n + 5)  # within capacity: data preserved (src/StlWrapper.cpp:231-236)
+        assert np.array_equal(a.to_host()[:, 0], (Xe if n >= 3 else X)[:, 0])
+        a.resize(n + 40)  # beyond capacity: re-allocation preserves data (:238-248)
+        assert np.array_equal(a.to_host()[:, 0], (Xe if n >= 3 else X)[:, 0])
+
+
+def test_random_matches_counter_generator(ctx, oracle):
+    ctx.set_seed(99, 5)
+    a = MV(ctx, m=1000, n=6, capacity=8)
+    a.random()
+    assert np.array_equal(a.to_host(), oracle.random(1000, 6, mode=1, seed=99, stream=5))
+    v = a.view(2)
+    v.random()  # next stream id, column index restarts at 0 inside the view
+    assert np.array_equal(v.to_host(), oracle.random(1000, 1, mode=1, seed=99, stream=6))
+    assert np.abs(a.to_host()).max() < 1.0
+
+
+def _csr_cases():
+    from rails_amd import problems as P
+
+    return {
+        "laplace7_small": P.laplace7(7, 5, 4),
+        "stencil27_rand": P.stencil27(9, 8, 7, random_values=True, seed=3),
+        "banded": P.banded_random(5000, 27, 300, seed=1),
+        "uniform": P.uniform_random(3001, 11, seed=2),
+        "dense": P.dense_to_csr(np.random.default_rng(5).uniform(-1, 1, (70, 70))),
+    }
+
+
+@pytest.mark.parametrize("name", ["laplace7_small", "stencil27_rand", "banded", "uniform", "dense"])
+def test_spmm_matches_oracle(ctx, oracle, name):
+    import rails_amd
+
+    A = _csr_cases()[name]
+    m = A[0].size - 1
+    op = rails_amd.HipOperatorWrapper(ctx, *A)
+    g = np.random.default_rng(11)
+    nnz_row = max(1, A[1].size // m)
+    for nc, xoff, yoff in ((1, 0, 0), (3, 0, 0), (8, 0, 2), (16, 16, 0), (17, 1, 0), (64, 0, 1), (128, 0, 0), (130, 2, 4)):
+        Xh = g.uniform(-1, 1, (m, nc))
+        big = MV(ctx, m=m, n=nc + xoff, capacity=nc + xoff)
+        X = big.view(xoff, xoff + nc - 1) if nc > 1 else big.view(xoff)
+        X.from_host(Xh)
+        outp = MV(ctx, m=m, n=nc + yoff, capacity=nc + yoff + 3)
+        Y = outp.view(yoff, yoff + nc - 1) if nc > 1 else outp.view(yoff)
+        op.apply(X, Y)
+        ref = oracle.csr_spmm(*A, Xh)
+        scale = np.abs(ref).max() + 1e-300
+        assert np.abs(Y.to_host() - ref).max() <= 1e-14 * np.sqrt(nnz_row) * scale * 4
+        # transposed apply (GenericOperatorWrapper_test.cpp:91-109)
+        opT = op.transpose()
+        YT = opT.apply(X)
+        rowptr, col, val = A
+        dense = np.zeros((m, m)) if m <= 400 else None
+        if dense is not None:
+            for i in range(m):
+                for p in range(rowptr[i], rowptr[i + 1]):
+                    dense[i, col[p]] += val[p]
+            np.testing.assert_allclose(YT.to_host(), dense.T @ Xh, atol=1e-13 * scale * nnz_row)
+
+
+def test_spmm_ragged_and_empty_rows(ctx, oracle):
+    import rails_amd
+
+    # rows with 0, 1 and many entries; last row empty
+    rowptr = np.array([0, 0, 1, 1, 40, 43, 43], dtype=np.int64)
+    g = np.random.default_rng(2)
+    col = g.integers(0, 6, 43).astype(np.int32)
+    val = g.uniform(-1, 1, 43)
+    op = rails_amd.HipOperatorWrapper(ctx, rowptr, col, val)
+    Xh = g.uniform(-1, 1, (6, 5))
+    Y = op.apply(MV(ctx, Xh))
+    np.testing.assert_allclose(Y.to_host(), oracle.csr_spmm(rowptr, col, val, Xh), atol=1e-14)
+
+
+def test_csr_create_rejects_bad_indices(ctx):
+    import rails_amd
+
+    with pytest.raises(rails_amd.RailsError):
+        rails_amd.HipOperatorWrapper(ctx, np.array([0, 1]), np.array([5], dtype=np.int32), np.array([1.0]))
+
+
+@pytest.mark.parametrize("m", [1, 63, 1000, 20011])
+def test_gram_matches_oracle(ctx, oracle, m):
+    g = np.random.default_rng(m)
+    for a, b in ((1, 1), (3, 5), (16, 16), (40, 8), (130, 16), (16, 130), (64, 33), (17, 1)):
+        Xh = g.uniform(-1, 1, (m, a))
+        Yh = g.uniform(-1, 1, (m, b))
+        X, Y = MV(ctx, Xh), MV(ctx, Yh)
+        C = X.dot(Y)
+        ref = oracle.dot(Xh, Yh)
+        assert C.shape == (a, b)
+        assert np.abs(C - ref).max() <= 1e-14 * m + 1e-13 * np.sqrt(m)
+
+
+def test_dot_on_views_and_norm(ctx, oracle):
+    g = np.random.default_rng(4)
+    Xh = g.uniform(-1, 1, (3000, 9))
+    X = MV(ctx, Xh)
+    C = X.view(1, 3).dot(X.view(4, 8))
+    np.testing.assert_allclose(C, Xh[:, 1:4].T @ Xh[:, 4:9], atol=1e-11)
+    # norm() = spectral 2-norm (F7), single column = Euclidean
+    assert abs(X.norm() - oracle.norm2(Xh)) < 1e-11
+    assert abs(X.view(2).norm() - np.linalg.norm(Xh[:, 2])) < 1e-11
+
+
+@pytest.mark.parametrize("m", [1, 50, 4097])
+def test_panel_gemm_matches_oracle(ctx, oracle, m):
+    g = np.random.default_rng(m + 1)
+    for k, r in ((1, 1), (5, 3), (16, 16), (33, 7), (64, 64), (200, 128), (20, 16), (129, 40), (40, 200)):
+        Xh = g.uniform(-1, 1, (m, k))
+        Ch = g.uniform(-1, 1, (k, r))
+        X = MV(ctx, Xh)
+        Y = X.matmul(Ch)
+        ref = oracle.panel_gemm(Xh, Ch)
+        assert np.abs(Y.to_host() - ref).max() <= 1e-14 * k * 4
+        # beta != 0 and alpha != 1 into an offset window
+        Y0 = g.uniform(-1, 1, (m, r + 1))
+        out = MV(ctx, Y0, capacity=r + 1)
+        X.gemm_into(Ch, out.view(1, r) if r > 1 else out.view(1), alpha=-1.0, beta=1.0)
+        ref2 = Y0.copy()
+        ref2[:, 1:] -= Xh @ Ch
+        assert np.abs(out.to_host() - ref2).max() <= 1e-14 * k * 4 + 1e-15
+    # in place: V.view(0, r-1) = V * X  (src/LyapunovSolver.hpp:265)
+    Xh = g.uniform(-1, 1, (m, 40))
+    Ch = g.uniform(-1, 1, (40, 24))
+    X = MV(ctx, Xh)
+    X.gemm_into(Ch, X.view(0, 23))
+    np.testing.assert_allclose(X.to_host()[:, :24], Xh @ Ch, atol=1e-12)
+    np.testing.assert_array_equal(X.to_host()[:, 24:], Xh[:, 24:])
+
+
+def test_orthogonalize_kat(ctx):
+    # test/GenericMultiVectorWrapper_test.cpp:270-311
+    a = np.zeros((10, 2))
+    a[0, 0], a[0, 1], a[1, 1] = 2.3, 5.3, 2.7
+    e = np.zeros((10, 2))
+    e[0, 0] = e[1, 1] = 1.0
+    for method in (0, 1, 2):
+        X = MV(ctx, a)
+        X.orthogonalize(method)
+        np.testing.assert_allclose(X.to_host(), e, atol=4e-16)
+    # watermark: orthogonalize one column, push_back, orthogonalize again
+    X = MV(ctx, a[:, :1], capacity=4)
+    X.orthogonalize()
+    c = np.zeros((10, 1))
+    c[0, 0], c[1, 0] = 5.3, 2.7
+    X.push_back(MV(ctx, c))
+    X.orthogonalize()
+    np.testing.assert_allclose(X.to_host(), e, atol=4e-16)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_orthogonalize_matches_oracle(ctx, oracle, method):
+    g = np.random.default_rng(8)
+    m = 6000
+    V1 = g.uniform(-1, 1, (m, 20))
+    V2 = g.uniform(-1, 1, (m, 16))
+    X = MV(ctx, V1, capacity=40)
+    used = X.orthogonalize(method)
+    assert used == (1 if method == 1 else 2)
+    o1 = oracle.orthogonalize(V1)
+    np.testing.assert_allclose(X.to_host(), o1, atol=1e-12)
+    X.push_back(MV(ctx, V2))
+    X.orthogonalize(method)
+    Q = X.to_host()
+    o12 = oracle.orthogonalize(np.hstack([o1, V2]), start=20)
+    np.testing.assert_allclose(Q, o12, atol=1e-11)
+    assert np.abs(Q.T @ Q - np.eye(36)).max() < 5e-15 * np.sqrt(m)
+
+
+def test_orthogonalize_rank_deficient_falls_back(ctx):
+    g = np.random.default_rng(9)
+    m = 2000
+    V1 = np.linalg.qr(g.uniform(-1, 1, (m, 6)))[0]
+    # (a) a new column that lies in span(V_old) up to 1e-13: after projection it is pure rounding noise, which
+    # both the reference's recurrence and the block form normalise (src/StlWrapper.cpp:318); the other columns
+    # must come out orthonormal either way
+    W = np.hstack([g.uniform(-1, 1, (m, 2)), V1[:, :1] + 1e-13 * g.uniform(-1, 1, (m, 1))])
+    X = MV(ctx, np.hstack([V1, W]), capacity=12)
+    X.orthogonalized = 6
+    used = X.orthogonalize(0)
+    assert used in (1, 2)
+    Q = X.to_host()
+    assert np.abs(Q[:, :8].T @ Q[:, :8] - np.eye(8)).max() < 1e-13
+    assert np.all(np.isfinite(Q))
+    # (b) two identical new columns: the block Gram matrix is singular -> column-wise recurrence of the reference
+    w = g.uniform(-1, 1, (m, 1))
+    X = MV(ctx, np.hstack([V1, w, w, g.uniform(-1, 1, (m, 1))]), capacity=12)
+    X.orthogonalized = 6
+    used = X.orthogonalize(0)
+    assert used == 1
+    Q = X.to_host()
+    assert np.all(np.isfinite(Q))
+    keep = [0, 1, 2, 3, 4, 5, 6, 8]
+    assert np.abs(Q[:, keep].T @ Q[:, keep] - np.eye(8)).max() < 1e-13
+
+
+def _lanczos_case(g, m, k, p):
+    A = g.uniform(-1, 1, (m, 6))  # low-rank-ish operator pieces keep this cheap on the CPU
+    V = np.linalg.qr(g.uniform(-1, 1, (m, k)))[0]
+    AV = A @ (A.T @ V) / m - 2.0 * V + 0.1 * g.uniform(-1, 1, (m, k))
+    B = g.uniform(-1, 1, (m, p))
+    T = g.uniform(-1, 1, (k, k))
+    T = 0.05 * (T + T.T)
+    return AV, V, T, B
+
+
+@pytest.mark.parametrize("m,k,p,L", [(240, 12, 4, 10), (5000, 40, 8, 12), (3001, 130, 16, 10), (777, 3, 1, 6)])
+def test_resid_lanczos_matches_oracle(ctx, oracle, m, k, p, L):
+    import rails_amd
+
+    g = np.random.default_rng(m)
+    AVh, Vh, T, Bh = _lanczos_case(g, m, k, p)
+    AV, V, B = MV(ctx, AVh, capacity=k + 6), MV(ctx, Vh, capacity=k + 2), MV(ctx, Bh)
+    ctx.set_seed(4242, 17)
+    out = rails_amd.resid_lanczos(ctx, AV, V, T, B, L)
+    ref = oracle.resid_lanczos(AVh, Vh, T, Bh, L, rng_mode=1, seed=4242, stream=17)
+    n = ref["steps"]
+    assert out["steps"] == n
+    scale = np.abs(ref["H"]).max()
+    # tridiagonal entries: same recurrence, different summation order -> compare to 1e-9 relative
+    np.testing.assert_allclose(out["H"][:n, :n], ref["H"][:n, :n], rtol=0, atol=1e-9 * scale)
+    np.testing.assert_allclose(out["eigenvalues"], ref["eigenvalues"], rtol=0, atol=1e-9 * scale)
+    # eigenvectors = Q * v  (src/LyapunovSolver.hpp:443), compared up to sign
+    E = MV(ctx, m=m, n=n, capacity=n)
+    rails_amd.lanczos_vectors(ctx, out["v"], E)
+    Eh = E.to_host()
+    R = ref["eigenvectors"]
+    s = np.sign((Eh * R).sum(0))
+    s[s == 0] = 1
+    # Ritz vectors of well separated Ritz values only (clusters rotate freely)
+    w = ref["eigenvalues"]
+    gap = np.array([min(abs(w[i] - w[j]) for j in range(n) if j != i) for i in range(n)])
+    good = gap > 1e-3 * scale
+    assert good.sum() >= 1
+    small_rank = 2 * k + p <= L + 2  # Krylov space (nearly) exhausted: Ritz vectors are ill-conditioned
+    assert np.abs(Eh * s - R)[:, good].max() < (1e-4 if small_rank else 1e-7)
+    # the Lanczos basis itself is orthonormal to the level the recurrence allows
+    Q = MV(ctx, m=m, n=n, capacity=n)
+    rails_amd.lanczos_vectors(ctx, np.eye(n), Q)
+    np.testing.assert_allclose(Q.to_host(), ref["Q"], atol=1e-5 if small_rank else 1e-8)
+
+
+def test_resid_lanczos_breakdown(ctx, oracle):
+    """beta < 1e-14 exit (src/LyapunovSolver.hpp:419-426): R of rank 1 from B alone (T = 0)."""
+    import rails_amd
+
+    m, k = 500, 2
+    g = np.random.default_rng(1)
+    Vh = np.linalg.qr(g.uniform(-1, 1, (m, k)))[0]
+    AVh = g.uniform(-1, 1, (m, k))
+    Bh = g.uniform(-1, 1, (m, 1))
+    T = np.zeros((k, k))
+    ctx.set_seed(7, 0)
+    out = rails_amd.resid_lanczos(ctx, MV(ctx, AVh), MV(ctx, Vh), T, MV(ctx, Bh), 8)
+    ref = oracle.resid_lanczos(AVh, Vh, T, Bh, 8, rng_mode=1, seed=7, stream=0)
+    # rank-1 operator: the Krylov space is exhausted after 2 vectors; both implementations either break
+    # down or continue on rounding noise.  The dominant Ritz value is ||B||^2 either way.
+    assert abs(np.abs(out["eigenvalues"]).max() - float(Bh.T @ Bh)) < 1e-9 * float(Bh.T @ Bh)
+    assert abs(np.abs(ref["eigenvalues"]).max() - float(Bh.T @ Bh)) < 1e-9 * float(Bh.T @ Bh)
+    assert out["steps"] <= 8
