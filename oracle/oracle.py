@@ -129,6 +129,18 @@ class Oracle:
     def srand(self, s):
         self.lib.orc_srand(s)
 
+    def set_partition(self, allreduce=None, halo=None, plan=None, m_global=0):
+        """Row-partitioned mode for the world_size > 1 CPU tests: allreduce(ptr, n, stream) and
+        halo(send_ptr, recv_ptr, ncols, stream) are the hooks of rails_amd.partition (host buffers here)."""
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)
+        HL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+        self._ar = AR((lambda buf, n: int(allreduce(buf or 0, n, 0) or 0))) if allreduce else C.cast(None, AR)
+        self._hl = HL((lambda s, r, nc: int(halo(s or 0, r or 0, nc, 0) or 0))) if halo else C.cast(None, HL)
+        rows = np.ascontiguousarray(plan.send_rows if plan is not None else np.zeros(0), dtype=np.int64)
+        self.lib.orc_set_partition.argtypes = [AR, HL, _i64p, C.c_int64, C.c_int64, C.c_int64]
+        self.lib.orc_set_partition(self._ar, self._hl, rows.ctypes.data_as(_i64p), rows.size, plan.n_ghost if plan is not None else 0,
+                                   m_global)
+
     def num_threads(self):
         return self.lib.orc_num_threads()
 
@@ -172,6 +184,18 @@ class Oracle:
         Y = np.zeros((m, X.shape[1]), order="F")
         self.lib.orc_csr_spmm(m, rowptr.ctypes.data_as(_i64p), col.ctypes.data_as(_i32p), _p(val), X.shape[1], _p(X),
                               X.shape[0], _p(Y), m)
+        return Y
+
+    def op_apply(self, rowptr, col, val, X):
+        """A * X in the current partition mode (local rows; ghosts through the halo hook)."""
+        X = _f(X)
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        m = rowptr.size - 1
+        Y = np.zeros((m, X.shape[1]), order="F")
+        self.lib.orc_op_apply.argtypes = [C.c_int, _i64p, _i32p, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int]
+        self.lib.orc_op_apply(m, rowptr.ctypes.data_as(_i64p), col.ctypes.data_as(_i32p), _p(val), X.shape[1], _p(X), X.shape[0], _p(Y), m)
         return Y
 
     def find_largest(self, vals, N):

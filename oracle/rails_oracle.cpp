@@ -124,6 +124,17 @@ namespace {
 // ----------------------------------------------------------------------------
 const int ROWCHUNK = 2048;
 
+// Row-partitioned runs (world_size > 1 CPU tests): every reduction over rows is summed over the ranks through
+// this hook, and the operator apply fetches ghost rows through the halo hook -- the same two exchanges the
+// HIP library makes (include/rails_hip.h: rails_allreduce_fn, rails_halo_fn).
+typedef int (*orc_allreduce_fn)(double *buf, size_t n);
+typedef int (*orc_halo_fn)(const double *send, double *recv, int ncols);
+orc_allreduce_fn g_allreduce = nullptr;
+orc_halo_fn g_halo = nullptr;
+std::vector<int64_t> g_send_rows;
+int64_t g_n_ghost = 0;
+int64_t g_m_global = 0;
+
 // C (a x b, ldc) = X^T Y ; X is m x a (ldx), Y is m x b (ldy).  src/StlWrapper.cpp:394-412
 void gemm_tn(int m, int a, int b, const double *X, int ldx, const double *Y, int ldy, double *C,
              int ldc)
@@ -146,12 +157,16 @@ void gemm_tn(int m, int a, int b, const double *X, int ldx, const double *Y, int
             }
         }
     }
+    std::vector<double> packed((size_t)a * b);
     for (int j = 0; j < b; ++j)
         for (int i = 0; i < a; ++i) {
             double s = 0.0;
             for (int c = 0; c < nch; ++c) s += part[(size_t)c * a * b + i + (size_t)j * a];
-            C[i + (size_t)j * ldc] = s;
+            packed[i + (size_t)j * a] = s;
         }
+    if (g_allreduce) g_allreduce(packed.data(), packed.size());
+    for (int j = 0; j < b; ++j)
+        for (int i = 0; i < a; ++i) C[i + (size_t)j * ldc] = packed[i + (size_t)j * a];
 }
 
 // Y (m x r, ldy) = beta*Y + alpha * X (m x k, ldx) * C (k x r, ldc).  src/StlWrapper.cpp:168-187
@@ -335,7 +350,21 @@ void op_apply(const Op &A, int nc, const double *X, int ldx, double *Y, int ldy)
             memcpy(Y + (size_t)j * ldy, X + (size_t)j * ldx, sizeof(double) * A.m);
     } else if (A.dense)
         gemm_nn(A.m, A.m, nc, 1.0, A.dense, A.ldd, X, ldx, 0.0, Y, ldy);
-    else
+    else if (g_halo && !A.identity) {
+        // [local rows ; ghost rows] of X, ghosts fetched from their owners (packed row-major per destination)
+        const int64_t ns = (int64_t)g_send_rows.size(), ng = g_n_ghost;
+        std::vector<double> send((size_t)std::max<int64_t>(ns, 1) * nc), recv((size_t)std::max<int64_t>(ng, 1) * nc);
+        for (int64_t i = 0; i < ns; ++i)
+            for (int j = 0; j < nc; ++j) send[(size_t)i * nc + j] = X[g_send_rows[i] + (size_t)j * ldx];
+        g_halo(send.data(), recv.data(), nc);
+        const int64_t me = A.m + ng;
+        std::vector<double> Xe((size_t)me * nc);
+        for (int j = 0; j < nc; ++j) {
+            memcpy(&Xe[(size_t)j * me], X + (size_t)j * ldx, sizeof(double) * A.m);
+            for (int64_t i = 0; i < ng; ++i) Xe[(size_t)j * me + A.m + i] = recv[(size_t)i * nc + j];
+        }
+        csr_spmm(A.m, A.rowptr, A.col, A.val, nc, Xe.data(), (int)me, Y, ldy);
+    } else
         csr_spmm(A.m, A.rowptr, A.col, A.val, nc, X, ldx, Y, ldy);
 }
 
@@ -557,6 +586,16 @@ void orc_default_params(orc_params *p)
 }
 
 void orc_srand(unsigned s) { std::srand(s); }
+
+// row-partitioned mode: hooks + ghost plan (null hooks switch it off)
+void orc_set_partition(orc_allreduce_fn ar, orc_halo_fn halo, const int64_t *send_rows, int64_t n_send, int64_t n_ghost, int64_t m_global)
+{
+    g_allreduce = ar;
+    g_halo = halo;
+    g_send_rows.assign(send_rows, send_rows + (send_rows ? n_send : 0));
+    g_n_ghost = n_ghost;
+    g_m_global = m_global;
+}
 int orc_num_threads() { return omp_get_max_threads(); }
 void orc_set_num_threads(int n) { omp_set_num_threads(n); }
 
@@ -590,6 +629,16 @@ void orc_csr_spmm(int m, const int64_t *rp, const int32_t *ci, const double *va,
                   int ldx, double *Y, int ldy)
 {
     csr_spmm(m, rp, ci, va, nc, X, ldx, Y, ldy);
+}
+// operator apply in the current partition mode (ghost rows fetched through the halo hook)
+void orc_op_apply(int m, const int64_t *rp, const int32_t *ci, const double *va, int nc, const double *X, int ldx, double *Y, int ldy)
+{
+    Op A;
+    A.m = m;
+    A.rowptr = rp;
+    A.col = ci;
+    A.val = va;
+    op_apply(A, nc, X, ldx, Y, ldy);
 }
 void orc_find_largest(const double *vals, int n, int N, int *out)
 {
@@ -658,7 +707,7 @@ int orc_solve(int m, const double *Adense, int lda, const int64_t *rp, const int
     Mo.val = mva;
     Rng rng{prm->rng_mode, prm->seed, prm->stream0, prm->row0};
 
-    const int n = m;
+    const int n = g_m_global > 0 ? (int)g_m_global : m;
     int max_size = std::max(*k_io, std::min(prm->restart_size > 0 ? prm->restart_size : 100, n)); // :106
     int kV = *k_io;
     if (!prm->restart_from_solution) { // :108-115
