@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=125000, help="rows of the bounded CPU sample")
     ap.add_argument("--spmm-variant", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--spmm-only", action="store_true", help="kernel experiment: only the A*X timing, for several column counts")
+    ap.add_argument("--spmm-cols", default="128", help="comma list of column counts for --spmm-only")
     args = ap.parse_args()
 
     import torch
@@ -126,6 +128,30 @@ def main():
     A.set_variant(args.spmm_variant)
     nnz_local = int(rowptr[-1])
     log("[rank %d] setup %.1fs: %s, m_local=%d nnz=%d ghosts=%d" % (rank, time.time() - t_setup, desc, ml, nnz_local, halo_rows))
+
+    if args.spmm_only:
+        for kk in [int(x) for x in args.spmm_cols.split(",")]:
+            X = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk)
+            Y = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk)
+            X.random()
+            for variant in ((1, 2) if args.spmm_variant == 0 else (args.spmm_variant,)):
+                A.set_variant(variant)
+                try:
+                    for _ in range(3):
+                        A.apply(X, Y)
+                except rails_amd.RailsError as e:
+                    log("variant %d k=%d: not applicable (%s)" % (variant, kk, str(e)[:80]))
+                    continue
+                ctx.sync()
+                ctx.timer_start()
+                for _ in range(args.spmm_reps):
+                    A.apply(X, Y)
+                ms = ctx.timer_stop() / args.spmm_reps
+                ab = nnz_local * 12 + (ml + 1) * 4 + 2 * ml * kk * 8
+                print(json.dumps({"pattern": args.pattern, "kernel": A.last_kernel(), "variant": variant, "k": kk, "ms": ms,
+                                  "alg_GBs": ab / ms / 1e6, "frac": ab / ms / 1e6 / HBM_PEAK_GBS}), flush=True)
+            del X, Y
+        return
 
     # ---- roofline leg: Y = A * X with k = 128 columns, HIP events on the library's stream -------------
     kk = args.kspmm
@@ -183,6 +209,7 @@ def main():
         elapsed = float(t.item())
     its = K / elapsed
     hist = solver.history()
+    log("[rank %d] host sections (s, whole solve incl. warm-up): %s" % (rank, json.dumps(solver.profile())))
     log("[rank %d] %d trips in %.3fs -> %.2f it/s; Lanczos estimates %.3e -> %.3e; V.N()=%d" % (rank, K, elapsed, its, hist[0], hist[-1], solver.k))
 
     # ---- cpu_baseline: the oracle (port of the Stl path) on a bounded sample, rank 0, N = 1 ---------------

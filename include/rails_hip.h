@@ -199,6 +199,9 @@ void rails_sb03md(char dico, char job, char fact, char trans, int n, double *A, 
 void rails_dsyev(char jobz, char uplo, int n, double *a, int lda, double *w, int *info);
 /* src/LapackWrapper.hpp:18-19 */
 void rails_dsteqr(char compz, int n, double *d, double *e, double *z, int ldz, double *work, int *info);
+/* src/BlasWrapper.hpp:34-42 (DGEMM), for the small host products of the restart (X' (VAV X), src/LyapunovSolver.hpp:286) */
+void rails_dgemm(char transa, char transb, int m, int n, int k, double alpha, const double *A, int lda, const double *B,
+                 int ldb, double beta, double *C, int ldc);
 /* Cholesky (generalized projected solve, block orthogonalisation) */
 void rails_dpotrf(char uplo, int n, double *a, int lda, int *info);
 int rails_host_lapack_init(const char *path);

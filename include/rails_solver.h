@@ -50,6 +50,10 @@ int rails_solver_get_T(rails_solver *s, double *T_host, int ldt);     /* k x k *
 int rails_solver_trips(rails_solver *s);
 int rails_solver_history(rails_solver *s, double *res, int cap);      /* Lanczos estimates per trip; returns count */
 
+/* host wall-clock seconds per solver section of the last solve (JSON object; names follow the reference's profile
+ * sections, src/Timer.hpp:101-106: "Apply A", "Apply B", "Compute VAV", "dense_solve", "Residual Lanczos", ...) */
+int rails_solver_profile(rails_solver *s, char *buf, int cap);
+
 /* ||A X + X A' + B B'||_F / ||B B'||_F for X = V T V' evaluated on the device without forming X
  * (uses R = [AV V B] G [AV V B]'; test / reporting helper) */
 int rails_solver_relative_residual(rails_solver *s, double *rel);

@@ -108,6 +108,14 @@ class Oracle:
         L.orc_set_num_threads.argtypes = [C.c_int]
         if L.orc_lapack_init(os.environ.get("RAILS_LAPACK_LIB", "").encode()) != 0:
             raise RuntimeError("oracle: no LAPACK library found")
+        # OpenMP threads: never more than the CPUs this process may use (a GPU box gives one GPU's share of the host,
+        # 16 CPUs; 128 spinning threads on 16 cores turn every parallel region into milliseconds)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cap = int(os.environ.get("RAILS_ORACLE_THREADS", "16"))
+        L.orc_set_num_threads(max(1, min(avail, cap)))
 
     # ---- small helpers -------------------------------------------------------------------
     def params(self, d=None, **kw):

@@ -108,13 +108,23 @@ __global__ __launch_bounds__(256) void k_gram(const double *__restrict__ X, int 
     }
 }
 
-__global__ void k_reduce_partials(const double *__restrict__ partial, int64_t nslab, int64_t n, double *__restrict__ out)
+// out[e] = sum_t partial[t][e] in a fixed order: 16 interleaved strands per element, then the strands 0..15
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partial, int64_t nslab, int64_t n, double *__restrict__ out)
 {
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+    __shared__ double sh[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + tx;
     double s = 0.0;
-    for (int64_t t = 0; t < nslab; ++t) s += partial[t * n + e];
-    out[e] = s;
+    if (e < n)
+        for (int64_t t = ty; t < nslab; t += 16) s += partial[t * n + e];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < n) {
+        double r = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) r += sh[g][tx];
+        out[e] = r;
+    }
 }
 
 template <int TI, int TJ>
@@ -237,7 +247,7 @@ int rails_gram_dev(rails_ctx *c, const double *X, int ldx, const double *Y, int 
         launch_gram<2, 4>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
     else
         launch_gram<2, 4>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->ws, nslab, (int64_t)n, C_dev);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, c->stream, c->ws, nslab, (int64_t)n, C_dev);
     RAILS_HIP_CHECK(hipGetLastError());
     return RAILS_OK;
 }

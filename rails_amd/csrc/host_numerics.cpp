@@ -74,6 +74,15 @@ bool try_open(const std::string &path)
         dlclose(h);
         return false;
     }
+    // The projected matrices are a few hundred rows: threaded BLAS only adds fork/join latency to the thousands of
+    // small calls inside dgees/dtrsyl.  RAILS_LAPACK_THREADS overrides (default 1).
+    typedef void (*setthreads_t)(int);
+    setthreads_t st = (setthreads_t)dlsym(h, "scipy_openblas_set_num_threads");
+    if (!st) st = (setthreads_t)dlsym(h, "openblas_set_num_threads");
+    if (!st) st = (setthreads_t)dlsym(h, "MKL_Set_Num_Threads");
+    int nt = 1;
+    if (const char *e = getenv("RAILS_LAPACK_THREADS")) nt = atoi(e) > 0 ? atoi(e) : 1;
+    if (st) st(nt);
     g_lp = L;
     return true;
 }
@@ -147,6 +156,13 @@ extern "C" void rails_dsteqr(char compz, int n, double *d, double *e, double *z,
         return;
     }
     g_lp.dsteqr(&compz, &n, d, e, z, &ldz, work, info);
+}
+
+extern "C" void rails_dgemm(char ta, char tb, int m, int n, int k, double alpha, const double *A, int lda, const double *B, int ldb,
+                            double beta, double *C, int ldc)
+{
+    if (rails_host_lapack_init(nullptr) != RAILS_OK) return;
+    g_lp.dgemm(&ta, &tb, &m, &n, &k, &alpha, A, &lda, B, &ldb, &beta, C, &ldc);
 }
 
 extern "C" void rails_dpotrf(char uplo, int n, double *a, int lda, int *info)

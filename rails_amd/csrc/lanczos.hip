@@ -79,7 +79,7 @@ struct LzArgs {
 };
 
 // lane l owns column pairs (2(l+64c), 2(l+64c)+1), c < NCH, of AV and of MV, and pair l of B.
-template <int NCH>
+template <int NCH, int U>
 __global__ __launch_bounds__(256) void k_lanczos_pass(LzArgs a)
 {
     __shared__ double red[4][(4 * NCH + 2) * 64 + 1];
@@ -135,59 +135,79 @@ __global__ __launch_bounds__(256) void k_lanczos_pass(LzArgs a)
         if (!init) q_cur[row0 + lane] = qn; // store the normalised q_i
         double rvec = 0.0;
         const int nrows = (int)((a.m - row0) < 64 ? (a.m - row0) : 64);
-        for (int j = 0; j < nrows; ++j) {
-            const int64_t row = row0 + j;
-            v2f64 xav[NCH], xmv[NCH], xb;
-            const double *pav = a.AV + row * a.ldav + 2 * lane;
-            const double *pmv = a.MV + row * a.ldmv + 2 * lane;
+        // U rows per trip of the loop: their 2*NCH+1 row loads are all issued before the first reduction, the
+        // U wave reductions are independent chains (rows are independent of each other)
+        for (int j0 = 0; j0 < nrows; j0 += U) {
+            v2f64 xav[U][NCH], xmv[U][NCH], xb[U];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                xav[c] = (v2f64){0.0, 0.0};
-                xmv[c] = (v2f64){0.0, 0.0};
-                if (ok0[c]) {
-                    xav[c] = *reinterpret_cast<const v2f64 *>(pav + 128 * c);
-                    xmv[c] = *reinterpret_cast<const v2f64 *>(pmv + 128 * c);
-                    if (!ok1[c]) {
-                        xav[c].y = 0.0;
-                        xmv[c].y = 0.0;
-                    }
-                }
-            }
-            xb = (v2f64){0.0, 0.0};
-            if (bok0) {
-                xb = *reinterpret_cast<const v2f64 *>(a.B + row * a.ldb + 2 * lane);
-                if (!bok1) xb.y = 0.0;
-            }
-            double r;
-            const double qi = readlane_f64(qn, j);
-            if (init) {
-                r = qi;
-            } else {
-                double t = 0.0;
+            for (int u = 0; u < U; ++u) {
+                const bool rok = (j0 + u) < nrows;
+                const int64_t row = row0 + j0 + (rok ? u : 0);
+                const double *pav = a.AV + row * a.ldav + 2 * lane;
+                const double *pmv = a.MV + row * a.ldmv + 2 * lane;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    t = __builtin_fma(xav[c].x, gav[c].x, t);
-                    t = __builtin_fma(xav[c].y, gav[c].y, t);
-                    t = __builtin_fma(xmv[c].x, gmv[c].x, t);
-                    t = __builtin_fma(xmv[c].y, gmv[c].y, t);
+                    xav[u][c] = (v2f64){0.0, 0.0};
+                    xmv[u][c] = (v2f64){0.0, 0.0};
+                    if (ok0[c] && rok) {
+                        xav[u][c] = *reinterpret_cast<const v2f64 *>(pav + 128 * c);
+                        xmv[u][c] = *reinterpret_cast<const v2f64 *>(pmv + 128 * c);
+                        if (!ok1[c]) {
+                            xav[u][c].y = 0.0;
+                            xmv[u][c].y = 0.0;
+                        }
+                    }
                 }
-                t = __builtin_fma(xb.x, gb.x, t);
-                t = __builtin_fma(xb.y, gb.y, t);
-                const double total = wave_sum(t);
-                const double qmi = readlane_f64(qm, j);
-                r = total - alpha * qi - betap * qmi;
+                xb[u] = (v2f64){0.0, 0.0};
+                if (bok0 && rok) {
+                    xb[u] = *reinterpret_cast<const v2f64 *>(a.B + row * a.ldb + 2 * lane);
+                    if (!bok1) xb[u].y = 0.0;
+                }
+            }
+            double r[U];
+            if (init) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) r[u] = ((j0 + u) < nrows) ? readlane_f64(qn, (j0 + u) & 63) : 0.0;
+            } else {
+                double t[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    double tt = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        tt = __builtin_fma(xav[u][c].x, gav[c].x, tt);
+                        tt = __builtin_fma(xav[u][c].y, gav[c].y, tt);
+                        tt = __builtin_fma(xmv[u][c].x, gmv[c].x, tt);
+                        tt = __builtin_fma(xmv[u][c].y, gmv[c].y, tt);
+                    }
+                    tt = __builtin_fma(xb[u].x, gb.x, tt);
+                    tt = __builtin_fma(xb[u].y, gb.y, tt);
+                    t[u] = tt;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) t[u] = wave_sum(t[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int jj = (j0 + u) & 63;
+                    const double qi = readlane_f64(qn, jj);
+                    const double qmi = readlane_f64(qm, jj);
+                    r[u] = ((j0 + u) < nrows) ? (t[u] - alpha * qi - betap * qmi) : 0.0;
+                }
             }
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                cav[c].x = __builtin_fma(xav[c].x, r, cav[c].x);
-                cav[c].y = __builtin_fma(xav[c].y, r, cav[c].y);
-                cmv[c].x = __builtin_fma(xmv[c].x, r, cmv[c].x);
-                cmv[c].y = __builtin_fma(xmv[c].y, r, cmv[c].y);
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    cav[c].x = __builtin_fma(xav[u][c].x, r[u], cav[c].x);
+                    cav[c].y = __builtin_fma(xav[u][c].y, r[u], cav[c].y);
+                    cmv[c].x = __builtin_fma(xmv[u][c].x, r[u], cmv[c].x);
+                    cmv[c].y = __builtin_fma(xmv[u][c].y, r[u], cmv[c].y);
+                }
+                cb.x = __builtin_fma(xb[u].x, r[u], cb.x);
+                cb.y = __builtin_fma(xb[u].y, r[u], cb.y);
+                rr = __builtin_fma(r[u], r[u], rr);
+                rvec = (lane == j0 + u) ? r[u] : rvec;
             }
-            cb.x = __builtin_fma(xb.x, r, cb.x);
-            cb.y = __builtin_fma(xb.y, r, cb.y);
-            rr = __builtin_fma(r, r, rr);
-            rvec = (lane == j) ? r : rvec;
         }
         if (!init) q_next[row0 + lane] = rvec;
     }
@@ -230,13 +250,23 @@ __global__ __launch_bounds__(256) void k_lanczos_pass(LzArgs a)
     }
 }
 
-__global__ void k_lz_reduce(const double *__restrict__ partial, int nblocks, int n, double *__restrict__ out)
+// out[e] = sum over the blocks' partials, fixed order (16 interleaved strands, then strands 0..15)
+__global__ __launch_bounds__(1024) void k_lz_reduce(const double *__restrict__ partial, int nblocks, int n, double *__restrict__ out)
 {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+    __shared__ double sh[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
     double s = 0.0;
-    for (int t = 0; t < nblocks; ++t) s += partial[(int64_t)t * n + e];
-    out[e] = s;
+    if (e < n)
+        for (int t = ty; t < nblocks; t += 16) s += partial[(int64_t)t * n + e];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < n) {
+        double r = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) r += sh[g][tx];
+        out[e] = r;
+    }
 }
 
 // One block.  sums = [c'_AV (k) | c'_MV (k) | c'_B (p) | rr] (already all-reduced).
@@ -352,10 +382,39 @@ __global__ void k_lz_random(double *__restrict__ q, int64_t m, int64_t mpad, uin
     }
 }
 
-template <int NCH>
-void launch_pass(rails_ctx *c, const LzArgs &a, int nblocks)
+template <int NCH, int U>
+void launch_pass_u(rails_ctx *c, const LzArgs &a, int *nblocks_io, bool size_only)
 {
-    hipLaunchKernelGGL((k_lanczos_pass<NCH>), dim3(nblocks), dim3(256), 0, c->stream, a);
+    if (size_only) { // grid = resident blocks only (every block walks the row groups with a grid stride)
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_lanczos_pass<NCH, U>, 256, 0) != hipSuccess || occ < 1) occ = 2;
+        if (occ > 4) occ = 4;
+        *nblocks_io = c->num_cu * occ;
+        return;
+    }
+    hipLaunchKernelGGL((k_lanczos_pass<NCH, U>), dim3(*nblocks_io), dim3(256), 0, c->stream, a);
+}
+
+int lz_unroll()
+{
+    static int u = -1;
+    if (u < 0) {
+        const char *e = getenv("RAILS_LZ_UNROLL");
+        u = e ? atoi(e) : 2;
+        if (u != 1 && u != 2 && u != 4) u = 2;
+    }
+    return u;
+}
+
+void launch_pass(rails_ctx *c, const LzArgs &a, int nch, int *nblocks_io, bool size_only)
+{
+    int u = lz_unroll();
+    if (nch >= 3 && u > 2) u = 2;
+#define RAILS_LZ_CASE(N, UU) \
+    if (nch == N && u == UU) return launch_pass_u<N, UU>(c, a, nblocks_io, size_only);
+    RAILS_LZ_CASE(1, 1) RAILS_LZ_CASE(1, 2) RAILS_LZ_CASE(1, 4) RAILS_LZ_CASE(2, 1) RAILS_LZ_CASE(2, 2) RAILS_LZ_CASE(2, 4)
+    RAILS_LZ_CASE(3, 1) RAILS_LZ_CASE(3, 2) RAILS_LZ_CASE(4, 1) RAILS_LZ_CASE(4, 2)
+#undef RAILS_LZ_CASE
 }
 
 } // namespace
@@ -395,7 +454,13 @@ extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0
     S.steps = 0;
     const int ncoef = 2 * k + p + 1;
     int64_t ngroups = S.mpad / 64;
-    int nblocks = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)c->num_cu * 4);
+    const int nch = std::min(4, std::max(1, (k + 127) / 128));
+    int nblocks = 0;
+    {
+        LzArgs dummy;
+        launch_pass(c, dummy, nch, &nblocks, true);
+    }
+    nblocks = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)nblocks);
     if (nblocks < 1) nblocks = 1;
     // small device block: T | coef | sums | state(8) | alphas(L+2) | betas(L+2)
     size_t nsmall = (size_t)k * k + ncoef + ncoef + 8 + 2 * (size_t)(L + 2);
@@ -439,16 +504,10 @@ extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0
     a.coef = dcoef;
     a.state = dstate;
     a.partial = c->ws;
-    const int nch = std::max(1, (k + 127) / 128);
     for (int step = -1; step < L; ++step) {
         a.step = step;
-        switch (nch) {
-        case 1: launch_pass<1>(c, a, nblocks); break;
-        case 2: launch_pass<2>(c, a, nblocks); break;
-        case 3: launch_pass<3>(c, a, nblocks); break;
-        default: launch_pass<4>(c, a, nblocks); break;
-        }
-        hipLaunchKernelGGL(k_lz_reduce, dim3((ncoef + 255) / 256), dim3(256), 0, c->stream, c->ws, nblocks, ncoef, dsums);
+        launch_pass(c, a, nch, &nblocks, false);
+        hipLaunchKernelGGL(k_lz_reduce, dim3((ncoef + 63) / 64), dim3(1024), 0, c->stream, c->ws, nblocks, ncoef, dsums);
         RAILS_TRY(rails_allreduce_dev(c, dsums, (size_t)ncoef));
         hipLaunchKernelGGL(k_lz_small, dim3(1), dim3(256), 0, c->stream, dsums, dT, k, p, step, dcoef, dstate, dalpha, dbeta);
     }

@@ -1,5 +1,6 @@
 // solver_capi.cpp -- C ABI (include/rails_solver.h) over rails::Solver instantiated on the HIP backend.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
@@ -185,6 +186,23 @@ extern "C" int rails_solver_history(rails_solver *s, double *res, int cap)
     int n = (int)h.size();
     for (int i = 0; i < n && i < cap; ++i) res[i] = h[i];
     return n;
+}
+
+extern "C" int rails_solver_profile(rails_solver *s, char *buf, int cap)
+{
+    if (!s || !buf || cap < 2) return RAILS_EINVAL;
+    std::string out = "{";
+    bool first = true;
+    for (auto const &kv : s->solver->profile()) {
+        char tmp[256];
+        snprintf(tmp, sizeof(tmp), "%s\"%s\": %.6f", first ? "" : ", ", kv.first.c_str(), kv.second);
+        out += tmp;
+        first = false;
+    }
+    out += "}";
+    if ((int)out.size() + 1 > cap) return RAILS_EINVAL;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return RAILS_OK;
 }
 
 // ||R||_F with R = P G P^T, P = [AV MV B], G = [[0 T 0],[T 0 0],[0 0 I]]:  ||R||_F^2 = tr(G S G S), S = P^T P

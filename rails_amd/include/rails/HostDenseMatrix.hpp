@@ -143,17 +143,9 @@ public:
             std::cerr << "Incomplatible matrices of sizes " << M() << "x" << N() << " and " << o.M() << "x" << o.N() << std::endl;
             return out;
         }
-        const int K = N();
-        for (int j = 0; j < o.N(); ++j)
-            for (int i = 0; i < M(); ++i) {
-                double s = 0.0;
-                for (int l = 0; l < K; ++l) {
-                    double a = transpose_ ? data()[l + (size_t)i * m_max_] : data()[i + (size_t)l * m_max_];
-                    double b = o.transpose_ ? o.data()[j + (size_t)l * o.m_max_] : o.data()[l + (size_t)j * o.m_max_];
-                    s += a * b;
-                }
-                out(i, j) = s;
-            }
+        if (M() > 0 && o.N() > 0 && N() > 0)
+            rails_dgemm(transpose_ ? 'T' : 'N', o.transpose_ ? 'T' : 'N', M(), o.N(), N(), 1.0, data(), m_max_, o.data(), o.m_max_, 0.0, out.data(),
+                        out.m_max_);
         return out;
     }
 

@@ -17,8 +17,10 @@
 #define RAILS_LYAPUNOVSOLVER_HPP
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <functional>
+#include <map>
 #include <iostream>
 #include <locale>
 #include <string>
@@ -121,6 +123,20 @@ Type get_parameter(ParameterList &params, std::string const &name, Type def)
     return ret;
 }
 
+// Wall-clock accumulators under the reference's profile section names (src/Timer.hpp:101-106 RAILS_START_TIMER /
+// RAILS_END_TIMER; "Apply A", "Apply B", "Compute VAV", "dense_solve", "Residual Lanczos", ...).  Host time between
+// synchronisation points; the device side is profiled with rocprofv3.
+class ScopedTimer
+{
+    std::map<std::string, double> *acc_;
+    std::string name_;
+    std::chrono::steady_clock::time_point t0_;
+
+public:
+    ScopedTimer(std::map<std::string, double> *acc, const char *name) : acc_(acc), name_(name), t0_(std::chrono::steady_clock::now()) {}
+    ~ScopedTimer() { (*acc_)[name_] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(); }
+};
+
 template <class Matrix, class MultiVector, class DenseMatrix>
 class Solver;
 
@@ -207,6 +223,8 @@ public:
     void set_trip_callback(std::function<void(int)> cb) { on_trip_ = cb; }
     int trips() const { return trips_; }
     std::vector<double> const &residual_history() const { return res_hist_; }
+    std::map<std::string, double> const &profile() const { return profile_; }
+    void reset_profile() { profile_.clear(); }
     MatrixOrMultiVectorWrapper<Matrix, MultiVector> const &B() const { return B_; }
 
     // Solve A*V*T*V' + V*T*V'*A' + B*B' = 0                                (src/LyapunovSolver.hpp:100-346)
@@ -255,8 +273,15 @@ public:
             if (W.N()) {
                 int N_AV = AV.N();
                 int wn = W.N();
-                MultiVector AW = Ops::apply_append(A_, W, AV);      // :146 and :203
-                MultiVector BW = B_.transpose() * W;                // :150
+                MultiVector AW, BW;
+                {
+                    ScopedTimer t(&profile_, "Apply A");
+                    AW = Ops::apply_append(A_, W, AV); // :146 and :203
+                }
+                {
+                    ScopedTimer t(&profile_, "Apply B");
+                    BW = B_.transpose() * W; // :150
+                }
                 MultiVector MW;
                 if (use_mass_matrix_) MW = Ops::apply_append(M_, W, MV); // RAILSsolver.m:368-373
 
@@ -265,6 +290,7 @@ public:
                     BV.resize(0);
                 }
 
+                ScopedTimer tvav(&profile_, "Compute VAV");
                 int s = N_AV + wn;
                 VAV.resize(s, s); // keeps what was there (:165-166)
                 VBV.resize(s, s);
@@ -302,13 +328,19 @@ public:
                 BV.push_back(BW); // :204 (AV was extended by apply_append)
             }
 
-            if (use_mass_matrix_)
-                generalized_dense_solve(VAV, VBV, VMV, T);
-            else
-                dense_solve(VAV, VBV, T); // :209
+            {
+                ScopedTimer t(&profile_, "dense_solve");
+                if (use_mass_matrix_)
+                    generalized_dense_solve(VAV, VBV, VMV, T);
+                else
+                    dense_solve(VAV, VBV, T); // :209
+            }
 
             typename Ops::Lanczos lz; // :211-215
-            Ops::lanczos(*this, AV, use_mass_matrix_ ? MV : V, T, lanczos_iterations_, lz);
+            {
+                ScopedTimer t(&profile_, "Residual Lanczos");
+                Ops::lanczos(*this, AV, use_mass_matrix_ ? MV : V, T, lanczos_iterations_, lz);
+            }
 
             double res = lz.eigenvalues.norm_inf(); // :217
             res_hist_.push_back(res);
@@ -351,6 +383,7 @@ public:
                     std::cout << ". Trying to restart with " << (reduced_size_ > 0 ? reduced_size_ : V.N()) << " vectors" << std::endl;
                 }
 
+                ScopedTimer trs(&profile_, "Restart");
                 DenseMatrix X;
                 compute_restart_vectors(X, T, std::min(reduced_size_, V.N()), restart_tolerance_);
 
@@ -409,8 +442,14 @@ public:
 
             std::vector<int> indices; // :335-340
             find_largest_eigenvalues(lz.eigenvalues, indices, expand_vectors);
-            lz.append_to(V, indices, expand_vectors);
-            V.orthogonalize();
+            {
+                ScopedTimer t(&profile_, "Expand");
+                lz.append_to(V, indices, expand_vectors);
+            }
+            {
+                ScopedTimer t(&profile_, "Orthogonalize");
+                V.orthogonalize();
+            }
 
             W = V.view(N_V, N_V + expand_vectors - 1); // :342
         }
@@ -599,6 +638,7 @@ protected:
     int trips_;
     std::vector<double> res_hist_;
     std::function<void(int)> on_trip_;
+    std::map<std::string, double> profile_;
 };
 
 } // namespace rails

@@ -83,6 +83,13 @@ class Solver:
         self.lib.rails_solver_history(self.h, _p(out), out.size)
         return out[:n]
 
+    def profile(self):
+        """Host wall-clock seconds per solver section of the last solve (reference's profile section names)."""
+        import json
+        buf = C.create_string_buffer(4096)
+        check(self.lib.rails_solver_profile(self.h, buf, 4096), "rails_solver_profile")
+        return json.loads(buf.value.decode())
+
     def relative_residual(self):
         rel = C.c_double(0.0)
         check(self.lib.rails_solver_relative_residual(self.h, C.byref(rel)), "rails_solver_relative_residual")

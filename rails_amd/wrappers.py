@@ -92,7 +92,8 @@ class _Panel:
     def __init__(self, ctx, m, capacity):
         self.ctx = ctx
         h = C.c_void_p()
-        check(ctx.lib.rails_panel_create(ctx.h, m, capacity, C.byref(h)), "rails_panel_create")
+        m = int(m)
+        check(ctx.lib.rails_panel_create(ctx.h, m, int(capacity), C.byref(h)), "rails_panel_create")
         self.h = h
         self.m = m
 

@@ -104,3 +104,15 @@ def test_host_dsyev_and_dsteqr():
     lib.rails_dsteqr(b"I", n, dd.ctypes.data_as(dp), ee.ctypes.data_as(dp), z.ctypes.data_as(dp), n, work.ctypes.data_as(dp), C.byref(info))
     assert info.value == 0
     np.testing.assert_allclose(dd, w, atol=1e-13)
+
+
+def test_wrappers_instantiate_the_reference_solver_template():
+    """Compile-only (no link, no run): the reference's RAILS::Solver template accepts the HIP wrapper classes."""
+    import subprocess
+
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("/root/reference is only present in the build container")
+    cmd = ["g++", "-std=c++11", "-fsyntax-only", "-I/root/reference", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "rails_amd", "include"), os.path.join(ROOT, "tests", "integration", "reference_solver_instantiation.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

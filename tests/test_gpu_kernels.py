@@ -287,7 +287,8 @@ def test_resid_lanczos_matches_oracle(ctx, oracle, m, k, p, L):
     # the Lanczos basis itself is orthonormal to the level the recurrence allows
     Q = MV(ctx, m=m, n=n, capacity=n)
     rails_amd.lanczos_vectors(ctx, np.eye(n), Q)
-    np.testing.assert_allclose(Q.to_host(), ref["Q"], atol=1e-5 if small_rank else 1e-8)
+    nq = n - 2 if small_rank else n  # the last vectors of an exhausted Krylov space are rounding-level chaotic
+    np.testing.assert_allclose(Q.to_host()[:, :nq], ref["Q"][:, :nq], atol=1e-6 if small_rank else 1e-8)
 
 
 def test_resid_lanczos_breakdown(ctx, oracle):
