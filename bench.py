@@ -112,7 +112,12 @@ def main():
     t_setup = time.time()
     (rowptr, colg, val), B, mg, r0, desc = build_problem(args, rank, nranks)
     ml = args.m
-    stream = torch.cuda.current_stream().cuda_stream
+    # one non-default torch stream for everything: the library's kernels and torch.distributed's collectives (which
+    # order themselves against the CURRENT torch stream) then serialise without host synchronisation
+    tstream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream, "expected a non-default stream handle"
     ctx = rails_amd.Context(device=local_rank, stream=stream, seed=args.seed)
     ctx.set_partition(rank, nranks, r0, mg)
     if nranks > 1:

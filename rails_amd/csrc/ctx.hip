@@ -106,7 +106,8 @@ extern "C" int rails_ctx_set_allreduce(rails_ctx *c, rails_allreduce_fn fn, void
 
 int rails_allreduce_dev(rails_ctx *c, double *dev, size_t n)
 {
-    if (c->nranks <= 1 || n == 0) return RAILS_OK;
+    if (n == 0) return RAILS_OK;
+    if (c->nranks <= 1 && !c->allreduce) return RAILS_OK; // a hook installed on a single rank is still honoured
     if (!c->allreduce) {
         rails_set_error("row-partitioned run (nranks=%d) without an all-reduce hook", c->nranks);
         return RAILS_ECOMM;

@@ -271,13 +271,15 @@ __global__ __launch_bounds__(1024) void k_lz_reduce(const double *__restrict__ p
 
 // One block.  sums = [c'_AV (k) | c'_MV (k) | c'_B (p) | rr] (already all-reduced).
 // Writes the coefficients for the next pass, alpha/beta bookkeeping and the breakdown flag.
-__global__ __launch_bounds__(256) void k_lz_small(const double *__restrict__ sums, const double *__restrict__ T, int k, int p, int step,
-                                                  double *__restrict__ coef, double *__restrict__ state, double *__restrict__ alphas,
-                                                  double *__restrict__ betas)
+__global__ __launch_bounds__(1024) void k_lz_small(const double *__restrict__ sums, const double *__restrict__ T, int k, int p, int step,
+                                                   double *__restrict__ coef, double *__restrict__ state, double *__restrict__ alphas,
+                                                   double *__restrict__ betas)
 {
-    __shared__ double sh[256];
+    __shared__ double sh[1024];
+    __shared__ double part1[4][256], part2[4][256];
     if (state[3] != 0.0) return;
     const int tid = threadIdx.x;
+    const int jr = tid & 255, q = tid >> 8; // output row within a group of 256, quarter of the inner index
     const double rr = sums[2 * k + p];
     const double beta = sqrt(rr);
     const bool init = step < 0;
@@ -290,32 +292,43 @@ __global__ __launch_bounds__(256) void k_lz_small(const double *__restrict__ sum
         return;
     }
     const double inv = 1.0 / beta;
-    // g_AV = T (c_MV * inv),  g_MV = T (c_AV * inv),  g_B = c_B * inv
-    for (int j = tid; j < k; j += 256) {
+    // g_AV = T (c_MV * inv),  g_MV = T (c_AV * inv),  g_B = c_B * inv; the inner index is split over 4 strands that
+    // are summed in a fixed order
+    const int l0 = (int)(((int64_t)k * q) / 4), l1 = (int)(((int64_t)k * (q + 1)) / 4);
+    for (int j0 = 0; j0 < k; j0 += 256) {
+        const int j = j0 + jr;
         double s1 = 0.0, s2 = 0.0;
-        for (int l = 0; l < k; ++l) {
-            double t = T[j + (int64_t)l * k];
-            s1 = __builtin_fma(t, sums[k + l] * inv, s1);
-            s2 = __builtin_fma(t, sums[l] * inv, s2);
+        if (j < k)
+            for (int l = l0; l < l1; ++l) {
+                const double t = T[j + (int64_t)l * k];
+                s1 = __builtin_fma(t, sums[k + l] * inv, s1);
+                s2 = __builtin_fma(t, sums[l] * inv, s2);
+            }
+        part1[q][jr] = s1;
+        part2[q][jr] = s2;
+        __syncthreads();
+        if (q == 0 && j < k) {
+            coef[j] = ((part1[0][jr] + part1[1][jr]) + part1[2][jr]) + part1[3][jr];
+            coef[k + j] = ((part2[0][jr] + part2[1][jr]) + part2[2][jr]) + part2[3][jr];
         }
-        coef[j] = s1;
-        coef[k + j] = s2;
+        __syncthreads();
     }
-    for (int j = tid; j < p; j += 256) coef[2 * k + j] = sums[2 * k + j] * inv;
+    for (int j = tid; j < p; j += 1024) coef[2 * k + j] = sums[2 * k + j] * inv;
+    __threadfence_block();
     __syncthreads();
     // alpha_next = c_AV.g_AV + c_MV.g_MV + c_B.c_B
     double part = 0.0;
-    for (int j = tid; j < k; j += 256) {
+    for (int j = tid; j < k; j += 1024) {
         part = __builtin_fma(sums[j] * inv, coef[j], part);
         part = __builtin_fma(sums[k + j] * inv, coef[k + j], part);
     }
-    for (int j = tid; j < p; j += 256) {
+    for (int j = tid; j < p; j += 1024) {
         double cbv = sums[2 * k + j] * inv;
         part = __builtin_fma(cbv, cbv, part);
     }
     sh[tid] = part;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 512; s > 0; s >>= 1) {
         if (tid < s) sh[tid] += sh[tid + s];
         __syncthreads();
     }
@@ -400,8 +413,8 @@ int lz_unroll()
     static int u = -1;
     if (u < 0) {
         const char *e = getenv("RAILS_LZ_UNROLL");
-        u = e ? atoi(e) : 2;
-        if (u != 1 && u != 2 && u != 4) u = 2;
+        u = e ? atoi(e) : 4;
+        if (u != 1 && u != 2 && u != 4) u = 4;
     }
     return u;
 }
@@ -509,7 +522,7 @@ extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0
         launch_pass(c, a, nch, &nblocks, false);
         hipLaunchKernelGGL(k_lz_reduce, dim3((ncoef + 63) / 64), dim3(1024), 0, c->stream, c->ws, nblocks, ncoef, dsums);
         RAILS_TRY(rails_allreduce_dev(c, dsums, (size_t)ncoef));
-        hipLaunchKernelGGL(k_lz_small, dim3(1), dim3(256), 0, c->stream, dsums, dT, k, p, step, dcoef, dstate, dalpha, dbeta);
+        hipLaunchKernelGGL(k_lz_small, dim3(1), dim3(1024), 0, c->stream, dsums, dT, k, p, step, dcoef, dstate, dalpha, dbeta);
     }
     RAILS_HIP_CHECK(hipGetLastError());
     // read back state, alphas, betas (contiguous)

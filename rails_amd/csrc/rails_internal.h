@@ -104,8 +104,15 @@ struct rails_csr {
     int64_t n_tiles = 0;
     int32_t *t_fp_ptr = nullptr; // [n_tiles+1] offsets into t_fp
     int32_t *t_fp = nullptr;     // footprint column lists
-    uint16_t *t_lcol = nullptr;  // [nnz] local (footprint-relative) column of every nonzero
-    int max_fp = 0;
+    uint16_t *t_lcol = nullptr;  // [nnz] footprint-relative column of every nonzero, tile-major
+    int32_t *t_rowptr = nullptr; // [n_tiles+1] offsets into t_rows
+    int32_t *t_rows = nullptr;   // [m] rows of every tile
+    int64_t *t_nzptr = nullptr;  // [n_tiles+1] offsets into t_val / t_lcol
+    int32_t *t_rp = nullptr;     // [m + n_tiles] per-tile local row offsets (rows+1 per tile)
+    double *t_val = nullptr;     // [nnz] values, tile-major
+    int max_fp = 0, max_nz = 0;
+    double tile_reuse = 0.0;
+    bool tile_grid = false;
     const char *last_kernel = "";
 };
 

@@ -48,14 +48,19 @@ template <int LPR, int VEC, int RPG>
 __global__ __launch_bounds__(256) void k_spmm_rowgather(int64_t m, const int64_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ col, const double *__restrict__ val,
                                                         const double *__restrict__ X, int ldx, const double *__restrict__ Xg,
-                                                        int ldg, double *__restrict__ Y, int ldy, int nc)
+                                                        int ldg, double *__restrict__ Y, int ldy, int nc, int64_t blocks_per_xcd)
 {
     constexpr int GROUPS = 256 / LPR;
     constexpr int U = 8;
     const int g = threadIdx.x / LPR;
     const int l = threadIdx.x % LPR;
-    int64_t row_base = ((int64_t)blockIdx.x * GROUPS + g) * RPG;
-    if (LPR == 64) row_base = ((int64_t)blockIdx.x * GROUPS + __builtin_amdgcn_readfirstlane(g)) * RPG;
+    // XCD-aware block -> row-range map: blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), so giving
+    // XCD x the contiguous logical blocks [x*bpx, (x+1)*bpx) keeps the sliding window of gathered X rows of each XCD
+    // inside its own 4 MiB L2 (speed only: any placement computes the same rows).
+    int64_t lb = blockIdx.x;
+    if (blocks_per_xcd > 0) lb = (int64_t)(blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
+    int64_t row_base = (lb * GROUPS + g) * RPG;
+    if (LPR == 64) row_base = (lb * GROUPS + __builtin_amdgcn_readfirstlane(g)) * RPG;
 
     for (int rr = 0; rr < RPG; ++rr) {
         const int64_t row = row_base + rr;
@@ -108,6 +113,12 @@ __global__ void k_pack_rows(const int64_t *__restrict__ rows, int64_t n, const d
     }
 }
 
+int spmm_env(const char *name, int def)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : def;
+}
+
 template <int LPR, int VEC>
 int launch_rg(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc)
 {
@@ -115,9 +126,15 @@ int launch_rg(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const 
     constexpr int RPG = (LPR >= 32) ? 4 : 2;
     int64_t rows_per_block = (int64_t)GROUPS * RPG;
     int64_t grid = (A->m + rows_per_block - 1) / rows_per_block;
+    static const int xcd_aware = spmm_env("RAILS_SPMM_XCD", 1);
+    int64_t bpx = 0;
+    if (xcd_aware && grid >= 64) {
+        bpx = (grid + 7) / 8;
+        grid = bpx * 8;
+    }
     RAILS_REQUIRE(grid <= 0x7fffffffLL, "rails_spmm: grid too large");
     hipLaunchKernelGGL((k_spmm_rowgather<LPR, VEC, RPG>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col,
-                       A->val, X, ldx, Xg, ldg, Y, ldy, nc);
+                       A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx);
     return RAILS_OK;
 }
 
@@ -217,6 +234,11 @@ extern "C" int rails_csr_destroy(rails_csr *A)
     if (A->t_fp_ptr) hipFree(A->t_fp_ptr);
     if (A->t_fp) hipFree(A->t_fp);
     if (A->t_lcol) hipFree(A->t_lcol);
+    if (A->t_rowptr) hipFree(A->t_rowptr);
+    if (A->t_rows) hipFree(A->t_rows);
+    if (A->t_nzptr) hipFree(A->t_nzptr);
+    if (A->t_rp) hipFree(A->t_rp);
+    if (A->t_val) hipFree(A->t_val);
     delete A;
     return RAILS_OK;
 }
@@ -259,7 +281,8 @@ extern "C" int rails_csr_set_halo(rails_csr *A, int64_t n_send, const int64_t *s
     return RAILS_OK;
 }
 
-int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, double *Y, int ldy, int nc, bool *done);
+int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool vec2,
+                     bool *done);
 
 extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_panel *X, int xc0, int nc, rails_panel *Y, int yc0)
 {
@@ -313,14 +336,23 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         ldg = nc;
     }
     bool done = false;
-    if (A->variant != 1 && A->n_ghost == 0) RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Yp, Y->ld, nc, &done));
+    const bool vec2 = ((xc0 | yc0) & 1) == 0 && (ldg % 2 == 0);
+    if (A->variant != 1) RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, vec2, &done));
     if (!done) {
         RAILS_REQUIRE(A->variant != 2, "rails_spmm: LDS-staged kernel requested but not applicable to this operator/shape");
-        bool vec2 = ((xc0 | yc0) & 1) == 0 && (ldg % 2 == 0);
-        if (vec2)
-            RAILS_TRY((dispatch_rg<2>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
-        else
-            RAILS_TRY((dispatch_rg<1>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
+        // Column chunking: with cc columns per launch the window of X rows an XCD gathers from shrinks to
+        // window_rows * cc * 8 bytes; chunks run back to back so each pass finds its window in L2.
+        static const int chunk_env = spmm_env("RAILS_SPMM_CHUNK", 0);
+        int cc = chunk_env > 0 ? chunk_env : nc;
+        if (cc & 1) cc += 1;
+        for (int j0 = 0; j0 < nc; j0 += cc) {
+            int n = std::min(cc, nc - j0);
+            const double *xg = (Xg == Xp) ? Xp + j0 : Xg + j0;
+            if (vec2)
+                RAILS_TRY((dispatch_rg<2>(c, A, Xp + j0, X->ld, xg, ldg, Yp + j0, Y->ld, n)));
+            else
+                RAILS_TRY((dispatch_rg<1>(c, A, Xp + j0, X->ld, xg, ldg, Yp + j0, Y->ld, n)));
+        }
         A->last_kernel = "k_spmm_rowgather";
     }
     RAILS_HIP_CHECK(hipGetLastError());
@@ -328,11 +360,448 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
 }
 
 // -----------------------------------------------------------------------------------------
-// Kernel 2: LDS-staged footprint kernel -- placeholder until the tiling analysis is built
-// (rails_spmm_tiled reports done = false and the row-gather kernel runs).
+// Kernel 2: LDS-staged footprint kernel (k_spmm_tiled).
+//
+// Rows are grouped into tiles.  The set of X rows a tile touches (its column footprint, sorted) is computed once per
+// operator on the host; every nonzero gets a 16-bit index into its tile's footprint and the tile's (val, index)
+// pairs are stored tile-major.  A workgroup owns one tile: it copies the tile's CSR block into LDS once, then per
+// chunk of KC columns stages footprint x KC doubles of X in LDS (coalesced 64/128-B row segments) and every row of
+// the tile accumulates from LDS.  Each X row segment crosses the L2->CU fabric once per tile instead of once per
+// nonzero, and the inner loop has no global loads.
+//
+// Tiles: if the matrix is a structured-grid stencil in natural ordering (detected from the column offsets of a
+// sample of rows: 5/7/9/27-point patterns), tiles are bx x by x bz boxes of grid points, whose footprint is
+// (bx+2)(by+2)(bz+2) -- 9.6 uses per staged row for an 8x4x4 box of a 27-point stencil.  Otherwise tiles are runs of
+// consecutive rows (banded matrices, ~2.8 uses per staged row for a 27-point pattern) and the kernel is used only
+// when a staged row is used about twice or more.
 // -----------------------------------------------------------------------------------------
-int rails_spmm_tiled(rails_ctx *, rails_csr *, const double *, int, double *, int, int, bool *done)
+namespace {
+
+template <int KC>
+__global__ __launch_bounds__(256) void k_spmm_tiled(int64_t m, int64_t ntiles, const int32_t *__restrict__ t_rowptr /* tile row starts into t_rows */,
+                                                    const int32_t *__restrict__ t_rows, const int64_t *__restrict__ t_nzptr,
+                                                    const int32_t *__restrict__ t_rp /* per tile-row nz offsets, local to the tile */,
+                                                    const double *__restrict__ t_val, const uint16_t *__restrict__ t_lcol,
+                                                    const int32_t *__restrict__ fp_ptr, const int32_t *__restrict__ fp,
+                                                    const double *__restrict__ X, int ldx, const double *__restrict__ Xg, int ldg,
+                                                    double *__restrict__ Y, int ldy, int nc, int64_t tiles_per_xcd, int nz_cap, int xs_doubles)
+{
+    extern __shared__ double smem[];
+    constexpr int LPR = KC / 2;    // lanes per row, 2 doubles (16 B) each
+    constexpr int RPP = 256 / LPR; // rows per pass of the workgroup
+    // LDS carve-up (all 8-byte aligned): vals[nz_cap] | Xs[fp x KC] | rp[rows_cap+1] (int32) | lcols[nz_cap] (uint16)
+    int64_t t = blockIdx.x;
+    if (tiles_per_xcd > 0) t = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (t >= ntiles) return;
+    const int tr0 = t_rowptr[t];
+    const int nrows = t_rowptr[t + 1] - tr0;
+    const int64_t z0 = t_nzptr[t];
+    const int nz = (int)(t_nzptr[t + 1] - z0);
+    const int f0 = fp_ptr[t];
+    const int nf = fp_ptr[t + 1] - f0;
+    // LDS carve-up: vals[nz_cap] | Xs[xs_doubles] | rp[264] (int32) | lcols[nz_cap] (uint16)
+    double *vals = smem;
+    double *Xs = vals + nz_cap;
+    int32_t *rp = reinterpret_cast<int32_t *>(Xs + xs_doubles);
+    uint16_t *lcols = reinterpret_cast<uint16_t *>(rp + 264);
+    const int tid = threadIdx.x;
+    const int part = tid % LPR;
+
+    for (int i = tid; i < nz; i += 256) {
+        vals[i] = t_val[z0 + i];
+        lcols[i] = t_lcol[z0 + i];
+    }
+    for (int i = tid; i <= nrows; i += 256) rp[i] = t_rp[tr0 + t + i]; // nrows+1 offsets per tile
+    __syncthreads();
+
+    for (int c0 = 0; c0 < nc; c0 += KC) {
+        const int cidx = c0 + 2 * part;
+        for (int idx = tid; idx < nf * LPR; idx += 256) {
+            const int f = idx / LPR;
+            const int32_t c = fp[f0 + f];
+            const double *src = (c < m) ? (X + (int64_t)c * ldx) : (Xg + ((int64_t)c - m) * ldg);
+            double2_t v = (double2_t){0.0, 0.0};
+            if (cidx + 1 < nc)
+                v = *reinterpret_cast<const double2_t *>(src + cidx);
+            else if (cidx < nc)
+                v.x = src[cidx];
+            *reinterpret_cast<double2_t *>(&Xs[f * KC + 2 * part]) = v;
+        }
+        __syncthreads();
+        for (int i = tid / LPR; i < nrows; i += RPP) {
+            const int p0 = rp[i], p1 = rp[i + 1];
+            double2_t acc = (double2_t){0.0, 0.0};
+            int p = p0;
+            for (; p + 4 <= p1; p += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double a = vals[p + u];
+                    const double2_t x = *reinterpret_cast<const double2_t *>(&Xs[(int)lcols[p + u] * KC + 2 * part]);
+                    acc.x = __builtin_fma(a, x.x, acc.x);
+                    acc.y = __builtin_fma(a, x.y, acc.y);
+                }
+            }
+            for (; p < p1; ++p) {
+                const double a = vals[p];
+                const double2_t x = *reinterpret_cast<const double2_t *>(&Xs[(int)lcols[p] * KC + 2 * part]);
+                acc.x = __builtin_fma(a, x.x, acc.x);
+                acc.y = __builtin_fma(a, x.y, acc.y);
+            }
+            double *dst = Y + (int64_t)t_rows[tr0 + i] * ldy + cidx;
+            if (cidx + 1 < nc)
+                *reinterpret_cast<double2_t *>(dst) = acc;
+            else if (cidx < nc)
+                *dst = acc.x;
+        }
+        __syncthreads();
+    }
+}
+
+// Pipelined form of k_spmm_tiled: every thread keeps the source pointers of its NL staging slots in registers (the
+// footprint is the same for every column chunk), the loads of chunk c+1 are in flight while chunk c is consumed from
+// the other LDS buffer, one barrier per chunk.
+template <int KC, int NL>
+__global__ __launch_bounds__(256) void k_spmm_tiled_pipe(int64_t m, int64_t ntiles, const int32_t *__restrict__ t_rowptr,
+                                                         const int32_t *__restrict__ t_rows, const int64_t *__restrict__ t_nzptr,
+                                                         const int32_t *__restrict__ t_rp, const double *__restrict__ t_val,
+                                                         const uint16_t *__restrict__ t_lcol, const int32_t *__restrict__ fp_ptr,
+                                                         const int32_t *__restrict__ fp, const double *__restrict__ X, int ldx,
+                                                         const double *__restrict__ Xg, int ldg, double *__restrict__ Y, int ldy, int nc,
+                                                         int64_t tiles_per_xcd, int nz_cap, int xs_doubles)
+{
+    extern __shared__ double smem[];
+    constexpr int LPR = KC / 2;
+    constexpr int RPP = 256 / LPR;
+    int64_t t = blockIdx.x;
+    if (tiles_per_xcd > 0) t = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (t >= ntiles) return;
+    const int tr0 = t_rowptr[t];
+    const int nrows = t_rowptr[t + 1] - tr0;
+    const int64_t z0 = t_nzptr[t];
+    const int nz = (int)(t_nzptr[t + 1] - z0);
+    const int f0 = fp_ptr[t];
+    const int nf = fp_ptr[t + 1] - f0;
+    // LDS: vals[nz_cap] | Xs0[xs_doubles] | Xs1[xs_doubles] | rp[264] (int32) | lcols[nz_cap] (uint16)
+    double *vals = smem;
+    double *Xs0 = vals + nz_cap;
+    int32_t *rp = reinterpret_cast<int32_t *>(Xs0 + 2 * (size_t)xs_doubles);
+    uint16_t *lcols = reinterpret_cast<uint16_t *>(rp + 264);
+    const int tid = threadIdx.x;
+    const int part = tid % LPR;
+
+    const double *srcp[NL];
+    int dsto[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int idx = tid + 256 * i;
+        srcp[i] = nullptr;
+        dsto[i] = 0;
+        if (idx < nf * LPR) {
+            const int f = idx / LPR;
+            const int32_t c = fp[f0 + f];
+            srcp[i] = ((c < m) ? (X + (int64_t)c * ldx) : (Xg + ((int64_t)c - m) * ldg)) + 2 * part;
+            dsto[i] = f * KC + 2 * part;
+        }
+    }
+    // D column chunks are in flight in registers; chunk ci is written to LDS buffer (ci & 1) just before it is
+    // consumed, and its register slot is refilled with chunk ci + D.  One barrier per chunk.
+    constexpr int D = 4;
+    double2_t stage[D][NL];
+    const int nchunks = (nc + KC - 1) / KC;
+#define RAILS_LOAD_CHUNK(SLOT, CI)                                                              \
+    do {                                                                                        \
+        const int c0__ = (CI)*KC;                                                               \
+        const int cidx__ = c0__ + 2 * part;                                                     \
+        _Pragma("unroll") for (int i = 0; i < NL; ++i)                                          \
+        {                                                                                       \
+            stage[SLOT][i] = (double2_t){0.0, 0.0};                                             \
+            if (srcp[i]) {                                                                      \
+                if (cidx__ + 1 < nc)                                                            \
+                    stage[SLOT][i] = *reinterpret_cast<const double2_t *>(srcp[i] + c0__);      \
+                else if (cidx__ < nc)                                                           \
+                    stage[SLOT][i].x = srcp[i][c0__];                                           \
+            }                                                                                   \
+        }                                                                                       \
+    } while (0)
+
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nchunks) RAILS_LOAD_CHUNK(d, d);
+    for (int i = tid; i < nz; i += 256) {
+        vals[i] = t_val[z0 + i];
+        lcols[i] = t_lcol[z0 + i];
+    }
+    for (int i = tid; i <= nrows; i += 256) rp[i] = t_rp[tr0 + t + i];
+
+    for (int cbase = 0; cbase < nchunks; cbase += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int ci = cbase + d;
+            if (ci < nchunks) {
+                double *Xs = Xs0 + (size_t)(ci & 1) * xs_doubles;
+#pragma unroll
+                for (int i = 0; i < NL; ++i)
+                    if (srcp[i]) *reinterpret_cast<double2_t *>(&Xs[dsto[i]]) = stage[d][i];
+                if (ci + D < nchunks) RAILS_LOAD_CHUNK(d, ci + D);
+                __syncthreads();
+                const int cidx = ci * KC + 2 * part;
+                for (int i = tid / LPR; i < nrows; i += RPP) {
+                    const int p0 = rp[i], p1 = rp[i + 1];
+                    double2_t acc = (double2_t){0.0, 0.0};
+                    int p = p0;
+                    for (; p + 4 <= p1; p += 4) {
+                        double a[4];
+                        int lc[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            a[u] = vals[p + u];
+                            lc[u] = lcols[p + u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double2_t x = *reinterpret_cast<const double2_t *>(&Xs[lc[u] * KC + 2 * part]);
+                            acc.x = __builtin_fma(a[u], x.x, acc.x);
+                            acc.y = __builtin_fma(a[u], x.y, acc.y);
+                        }
+                    }
+                    for (; p < p1; ++p) {
+                        const double a = vals[p];
+                        const double2_t x = *reinterpret_cast<const double2_t *>(&Xs[(int)lcols[p] * KC + 2 * part]);
+                        acc.x = __builtin_fma(a, x.x, acc.x);
+                        acc.y = __builtin_fma(a, x.y, acc.y);
+                    }
+                    double *dst = Y + (int64_t)t_rows[tr0 + i] * ldy + cidx;
+                    if (cidx + 1 < nc)
+                        *reinterpret_cast<double2_t *>(dst) = acc;
+                    else if (cidx < nc)
+                        *dst = acc.x;
+                }
+            }
+        }
+    }
+#undef RAILS_LOAD_CHUNK
+}
+
+// Structured-grid detection from the column offsets of local columns: returns true and (nx, ny, nz) when every
+// sampled offset decomposes as dx + nx*dy + nx*ny*dz with |dx|,|dy|,|dz| <= 1.
+bool detect_grid(const rails_csr *A, int64_t *nx, int64_t *ny, int64_t *nz)
+{
+    const int64_t m = A->m;
+    if (m < 64) return false;
+    std::vector<int64_t> offs;
+    int64_t step = std::max<int64_t>(1, m / 4096);
+    for (int64_t r = 0; r < m; r += step)
+        for (int64_t p = A->h_rowptr[r]; p < A->h_rowptr[r + 1]; ++p) {
+            int64_t c = A->h_col[p];
+            if (c < m && c > r) offs.push_back(c - r);
+        }
+    std::sort(offs.begin(), offs.end());
+    offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+    if (offs.empty() || offs.size() > 13 || offs[0] != 1) return false;
+    auto has = [&](int64_t v) { return std::binary_search(offs.begin(), offs.end(), v); };
+    if (offs.size() < 2) return false;
+    int64_t a = offs[1]; // smallest offset > 1: nx (5/7-point) or nx-1 (9/27-point)
+    int64_t gx = (has(a + 1) && has(a + 2)) ? a + 1 : a;
+    if (gx < 3 || m % gx != 0) return false;
+    // offsets beyond the in-plane cluster {1, nx-1, nx, nx+1} form a symmetric cluster around nx*ny
+    int64_t gxy = 0, lo = 0, hi = 0;
+    for (int64_t v : offs)
+        if (v > gx + 1) {
+            if (!lo) lo = v;
+            hi = v;
+        }
+    if (lo) gxy = (lo + hi) / 2;
+    if (gxy && (gxy % gx != 0 || !has(gxy))) return false;
+    if (gxy == 0) gxy = m; // 2D grid
+    if (m % gxy != 0) return false;
+    // validate on the sample
+    for (int64_t r = 0; r < m; r += step)
+        for (int64_t p = A->h_rowptr[r]; p < A->h_rowptr[r + 1]; ++p) {
+            int64_t c = A->h_col[p];
+            if (c >= m) continue;
+            int64_t x = r % gx, y = (r % gxy) / gx, z = r / gxy;
+            int64_t cx = c % gx, cy = (c % gxy) / gx, cz = c / gxy;
+            if (std::llabs(cx - x) > 1 || std::llabs(cy - y) > 1 || std::llabs(cz - z) > 1) return false;
+        }
+    *nx = gx;
+    *ny = gxy / gx;
+    *nz = m / gxy;
+    return true;
+}
+
+struct TilePlan {
+    std::vector<int32_t> t_rowptr, t_rows, t_rp, fp_ptr, fp;
+    std::vector<int64_t> t_nzptr;
+    std::vector<double> t_val;
+    std::vector<uint16_t> t_lcol;
+    int max_fp = 0, max_nz = 0, max_rows = 0;
+    double reuse = 0.0;
+};
+
+// tile_of_row -> plan; returns false when a tile exceeds the caps
+bool make_plan(const rails_csr *A, const std::vector<int32_t> &tile_of_row, int64_t ntiles, int fp_cap, int nz_cap, TilePlan &P)
+{
+    const int64_t m = A->m;
+    P.t_rowptr.assign(ntiles + 1, 0);
+    for (int64_t r = 0; r < m; ++r) P.t_rowptr[tile_of_row[r] + 1]++;
+    for (int64_t t = 0; t < ntiles; ++t) P.t_rowptr[t + 1] += P.t_rowptr[t];
+    P.t_rows.resize(m);
+    {
+        std::vector<int32_t> next(P.t_rowptr.begin(), P.t_rowptr.end() - 1);
+        for (int64_t r = 0; r < m; ++r) P.t_rows[next[tile_of_row[r]]++] = (int32_t)r;
+    }
+    P.t_nzptr.assign(ntiles + 1, 0);
+    P.fp_ptr.assign(ntiles + 1, 0);
+    P.t_rp.resize((size_t)m + ntiles);
+    P.t_val.resize((size_t)A->nnz);
+    P.t_lcol.resize((size_t)A->nnz);
+    P.fp.reserve((size_t)A->nnz / 4 + 16);
+    std::vector<int32_t> tmp;
+    int64_t z = 0;
+    for (int64_t t = 0; t < ntiles; ++t) {
+        int r0 = P.t_rowptr[t], r1 = P.t_rowptr[t + 1];
+        if (r1 - r0 > 256) return false;
+        tmp.clear();
+        for (int i = r0; i < r1; ++i) {
+            int64_t r = P.t_rows[i];
+            tmp.insert(tmp.end(), A->h_col.begin() + A->h_rowptr[r], A->h_col.begin() + A->h_rowptr[r + 1]);
+        }
+        int nzt = (int)tmp.size();
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        if ((int)tmp.size() > fp_cap || nzt > nz_cap) return false;
+        int loc = 0;
+        for (int i = r0; i < r1; ++i) {
+            int64_t r = P.t_rows[i];
+            P.t_rp[(size_t)r0 + t + (i - r0)] = loc;
+            for (int64_t p = A->h_rowptr[r]; p < A->h_rowptr[r + 1]; ++p) {
+                P.t_val[z + loc] = A->h_val[p];
+                P.t_lcol[z + loc] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), A->h_col[p]) - tmp.begin());
+                loc++;
+            }
+        }
+        P.t_rp[(size_t)r0 + t + (r1 - r0)] = loc;
+        z += nzt;
+        P.t_nzptr[t + 1] = z;
+        P.fp.insert(P.fp.end(), tmp.begin(), tmp.end());
+        P.fp_ptr[t + 1] = (int32_t)P.fp.size();
+        P.max_fp = std::max(P.max_fp, (int)tmp.size());
+        P.max_nz = std::max(P.max_nz, nzt);
+        P.max_rows = std::max(P.max_rows, r1 - r0);
+    }
+    P.reuse = P.fp.empty() ? 0.0 : (double)A->nnz / (double)P.fp.size();
+    return true;
+}
+
+template <class T>
+int upload(T **dst, const std::vector<T> &src)
+{
+    size_t n = src.empty() ? 1 : src.size();
+    RAILS_HIP_CHECK(hipMalloc((void **)dst, n * sizeof(T)));
+    if (!src.empty()) RAILS_HIP_CHECK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RAILS_OK;
+}
+
+} // namespace
+
+int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool vec2,
+                     bool *done)
 {
     *done = false;
+    if (!vec2 || nc < 8 || A->nnz == 0 || A->m >= 0x7fffffffLL) return RAILS_OK;
+    static const int env_rows = spmm_env("RAILS_SPMM_TILE_ROWS", 128);
+    static const int env_kc = spmm_env("RAILS_SPMM_TILE_KC", 8);
+    static const int env_box = spmm_env("RAILS_SPMM_TILE_BOX", 1);
+    const int KC = (env_kc == 16) ? 16 : 8;
+    const int lds_budget = 150 * 1024;
+    if (!A->tiled_ready) {
+        A->tiled_ready = true;
+        A->tiled_ok = false;
+        const int64_t m = A->m;
+        std::vector<int32_t> tile_of_row(m);
+        int64_t ntiles = 0;
+        int64_t gx = 0, gy = 0, gz = 0;
+        bool grid = env_box && detect_grid(A, &gx, &gy, &gz);
+        if (grid) {
+            // box of about env_rows grid points: x longest (contiguous in memory), then y, then z
+            int bx = 8, by = 4, bz = 4;
+            if (env_rows <= 64) { bx = 4; by = 4; bz = 4; }
+            if (env_rows >= 256) { bx = 8; by = 8; bz = 4; }
+            if (gz == 1) { bz = 1; by = std::max(1, env_rows / bx); }
+            int64_t tx = (gx + bx - 1) / bx, ty = (gy + by - 1) / by, tz = (gz + bz - 1) / bz;
+            ntiles = tx * ty * tz;
+            for (int64_t r = 0; r < m; ++r) {
+                int64_t x = r % gx, y = (r / gx) % gy, z = r / (gx * gy);
+                tile_of_row[r] = (int32_t)((z / bz) * ty * tx + (y / by) * tx + (x / bx));
+            }
+        } else {
+            int rows = std::min(env_rows, 256);
+            ntiles = (m + rows - 1) / rows;
+            for (int64_t r = 0; r < m; ++r) tile_of_row[r] = (int32_t)(r / rows);
+        }
+        // caps from the LDS budget: vals 8 B + lcol 2 B per nonzero, KC*8 B per footprint row, 1 KiB of row offsets
+        TilePlan P;
+        int nz_cap = 256 * std::max(1, A->max_row_nnz);
+        int fp_cap = 65535;
+        if (make_plan(A, tile_of_row, ntiles, fp_cap, nz_cap, P)) {
+            size_t need = (size_t)((P.max_nz + 3) / 4 * 4) * 8 + (size_t)P.max_fp * KC * 8 + 264 * 4 + (size_t)((P.max_nz + 3) / 4 * 4) * 2 + 64;
+            if (P.reuse >= 1.8 && need <= (size_t)lds_budget) {
+                RAILS_TRY(upload(&A->t_rowptr, P.t_rowptr));
+                RAILS_TRY(upload(&A->t_rows, P.t_rows));
+                RAILS_TRY(upload(&A->t_nzptr, P.t_nzptr));
+                RAILS_TRY(upload(&A->t_rp, P.t_rp));
+                RAILS_TRY(upload(&A->t_val, P.t_val));
+                RAILS_TRY(upload(&A->t_lcol, P.t_lcol));
+                RAILS_TRY(upload(&A->t_fp_ptr, P.fp_ptr));
+                RAILS_TRY(upload(&A->t_fp, P.fp));
+                A->n_tiles = ntiles;
+                A->max_fp = P.max_fp;
+                A->max_nz = (P.max_nz + 3) / 4 * 4;
+                A->tile_rows = P.max_rows;
+                A->tile_reuse = P.reuse;
+                A->tile_grid = grid;
+                A->tiled_ok = true;
+            }
+        }
+    }
+    if (!A->tiled_ok) return RAILS_OK;
+    const int xs_doubles = A->max_fp * KC;
+    size_t lds = (size_t)A->max_nz * 8 + (size_t)xs_doubles * 8 + 264 * 4 + (size_t)A->max_nz * 2 + 64;
+    int64_t grid = A->n_tiles, tpx = 0;
+    static const int xcd_aware = spmm_env("RAILS_SPMM_XCD", 1);
+    if (xcd_aware && grid >= 64) {
+        tpx = (grid + 7) / 8;
+        grid = tpx * 8;
+    }
+    static const int env_pipe = spmm_env("RAILS_SPMM_TILE_PIPE", 1);
+    const int lpr = KC / 2;
+    const int need_nl = (A->max_fp * lpr + 255) / 256;
+    size_t lds_pipe = lds + (size_t)xs_doubles * 8;
+    bool pipe = env_pipe && need_nl <= 8 && lds_pipe <= (size_t)lds_budget;
+#define RAILS_TILED_ARGS A->m, A->n_tiles, A->t_rowptr, A->t_rows, A->t_nzptr, A->t_rp, A->t_val, A->t_lcol, A->t_fp_ptr, A->t_fp, X, ldx, Xg, ldg, Y, ldy, nc, tpx, A->max_nz, xs_doubles
+#define RAILS_LAUNCH_PIPE(KCV, NLV)                                                                                                    \
+    do {                                                                                                                               \
+        RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled_pipe<KCV, NLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)); \
+        hipLaunchKernelGGL((k_spmm_tiled_pipe<KCV, NLV>), dim3((unsigned)grid), dim3(256), lds_pipe, c->stream, RAILS_TILED_ARGS);  \
+    } while (0)
+    if (pipe) {
+        if (KC == 8) {
+            if (need_nl <= 4) RAILS_LAUNCH_PIPE(8, 4);
+            else RAILS_LAUNCH_PIPE(8, 8);
+        } else {
+            if (need_nl <= 4) RAILS_LAUNCH_PIPE(16, 4);
+            else RAILS_LAUNCH_PIPE(16, 8);
+        }
+    } else if (KC == 8) {
+        RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_spmm_tiled<8>), dim3((unsigned)grid), dim3(256), lds, c->stream, RAILS_TILED_ARGS);
+    } else {
+        RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_spmm_tiled<16>), dim3((unsigned)grid), dim3(256), lds, c->stream, RAILS_TILED_ARGS);
+    }
+#undef RAILS_LAUNCH_PIPE
+#undef RAILS_TILED_ARGS
+    A->last_kernel = pipe ? "k_spmm_tiled_pipe" : "k_spmm_tiled";
+    *done = true;
     return RAILS_OK;
 }

@@ -1,0 +1,69 @@
+"""The collective hooks on a real GPU: a world_size = 1 RCCL group (the most this 1-GPU box allows) drives the
+library's all-reduce hook through torch.distributed on device pointers and on the library's stream."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_allreduce_hook_over_rccl_single_rank(oracle):
+    import torch
+    import torch.distributed as dist
+
+    import rails_amd
+    from rails_amd import partition, problems as P
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ts = torch.cuda.Stream(device=0)
+        torch.cuda.set_stream(ts)
+        ctx = rails_amd.Context(device=0, stream=ts.cuda_stream, seed=5)
+        calls = []
+        inner = partition.make_allreduce(on_device=True)
+
+        def hook(ptr, n, stream):
+            calls.append(n)
+            return inner(ptr, n, stream)
+
+        ctx.set_allreduce(hook)
+        # wrap_buffer sees the library's device memory
+        g = np.random.default_rng(0)
+        Xh = g.uniform(-1, 1, (4000, 24))
+        X = rails_amd.HipMultiVectorWrapper(ctx, data=Xh)
+        t = partition.wrap_buffer(ctx.lib.rails_panel_device_ptr(X.panel.h), 4, True)
+        ctx.sync()
+        np.testing.assert_array_equal(t.cpu().numpy(), Xh[0, :4])
+        # Gram through the hook (sum over one rank = identity)
+        C = X.dot(X)
+        np.testing.assert_allclose(C, Xh.T @ Xh, atol=1e-10)
+        assert calls and calls[-1] == 24 * 24
+        # a whole solve with the hook in every reduction (Gram, Lanczos sums, orthogonalisation)
+        A = P.laplace7(12, 10, 8)
+        m = A[0].size - 1
+        B = P.rhs(m, 6, seed=3)
+        params = {"Restart size": 80, "Reduced size": 40, "Expand size": 4, "Lanczos iterations": 8, "Tolerance": 1e-6}
+        op = rails_amd.HipOperatorWrapper(ctx, *A)
+        ctx.set_seed(11, 0)
+        sv = rails_amd.Solver(ctx, op, B)
+        assert sv.set_parameters(params) == 0
+        sv.set_option("verbose", 0)
+        n0 = len(calls)
+        code, V, T = sv.solve()
+        assert code == 0 and len(calls) - n0 > 9 * sv.trips()  # one all-reduce per Lanczos step + projections
+        out = oracle.solve(A, B, oracle.params({**params, "rng_mode": 1, "seed": 11}))
+        Xg, Xo = V @ T @ V.T, out["V"] @ out["T"] @ out["V"].T
+        assert np.linalg.norm(Xg - Xo) / np.linalg.norm(Xo) < 1e-4
+        sv.close()
+        ctx.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream(0))
+        dist.destroy_process_group()

@@ -107,6 +107,36 @@ def test_spmm_matches_oracle(ctx, oracle, name):
             np.testing.assert_allclose(YT.to_host(), dense.T @ Xh, atol=1e-13 * scale * nnz_row)
 
 
+@pytest.mark.parametrize("name", ["laplace7_small", "stencil27_rand", "banded"])
+def test_spmm_lds_staged_kernel_matches_oracle(ctx, oracle, name):
+    """variant 2 = LDS-staged footprint kernel (k_spmm_tiled); bit-for-bit the same sums in the same order per row."""
+    import rails_amd
+    from rails_amd import problems as P
+
+    A = {"laplace7_small": P.laplace7(23, 11, 9), "stencil27_rand": P.stencil27(20, 12, 9, random_values=True, seed=3),
+         "banded": P.banded_random(5000, 27, 40, seed=1)}[name]
+    m = A[0].size - 1
+    op = rails_amd.HipOperatorWrapper(ctx, *A)
+    op.set_variant(2)
+    g = np.random.default_rng(13)
+    for nc, xoff, yoff in ((8, 0, 0), (16, 16, 0), (17, 0, 2), (64, 2, 0), (128, 0, 0), (130, 0, 0)):
+        Xh = g.uniform(-1, 1, (m, nc))
+        big = MV(ctx, m=m, n=nc + xoff, capacity=nc + xoff)
+        X = big.view(xoff, xoff + nc - 1)
+        X.from_host(Xh)
+        outp = MV(ctx, m=m, n=nc + yoff, capacity=nc + yoff + 3)
+        Y = outp.view(yoff, yoff + nc - 1)
+        op.apply(X, Y)
+        assert op.last_kernel().startswith("k_spmm_tiled")
+        ref = oracle.csr_spmm(*A, Xh)
+        assert np.abs(Y.to_host() - ref).max() <= 1e-14 * np.abs(ref).max() * 8
+    # no reuse between rows (uniform random columns): the kernel must refuse rather than run slowly
+    opu = rails_amd.HipOperatorWrapper(ctx, *P.uniform_random(3001, 11, seed=2))
+    opu.set_variant(2)
+    with pytest.raises(rails_amd.RailsError):
+        opu.apply(MV(ctx, g.uniform(-1, 1, (3001, 16))))
+
+
 def test_spmm_ragged_and_empty_rows(ctx, oracle):
     import rails_amd
 
