@@ -215,6 +215,7 @@ def main():
     its = K / elapsed
     hist = solver.history()
     log("[rank %d] host sections (s, whole solve incl. warm-up): %s" % (rank, json.dumps(solver.profile())))
+    log("[rank %d] counters: %s" % (rank, json.dumps(ctx.stats())))
     log("[rank %d] %d trips in %.3fs -> %.2f it/s; Lanczos estimates %.3e -> %.3e; V.N()=%d" % (rank, K, elapsed, its, hist[0], hist[-1], solver.k))
 
     # ---- cpu_baseline: the oracle (port of the Stl path) on a bounded sample, rank 0, N = 1 ---------------

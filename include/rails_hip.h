@@ -64,6 +64,8 @@ int rails_ctx_create(int device, void *stream, rails_ctx **out);
 int rails_ctx_destroy(rails_ctx *ctx);
 int rails_ctx_sync(rails_ctx *ctx);
 void *rails_ctx_stream(rails_ctx *ctx);
+/* call counters of this context as a JSON object (block vs column-wise orthogonalisations, SpMM kernel choice, ...) */
+int rails_ctx_stats(rails_ctx *ctx, char *buf, int cap);
 
 /* Counter-based RNG: value = f(seed, stream id, GLOBAL row, column); every random
  * fill consumes one stream id.  Replaces StlWrapper::random's std::rand()-seeded

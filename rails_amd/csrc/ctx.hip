@@ -74,6 +74,17 @@ extern "C" int rails_ctx_sync(rails_ctx *c)
     return RAILS_OK;
 }
 
+extern "C" int rails_ctx_stats(rails_ctx *c, char *buf, int cap)
+{
+    RAILS_REQUIRE(c && buf && cap > 0, "rails_ctx_stats: bad argument");
+    int n = snprintf(buf, (size_t)cap,
+                     "{\"orth_block\": %ld, \"orth_columnwise\": %ld, \"spmm_tiled\": %ld, \"spmm_rowgather\": %ld, \"allreduce\": %ld, "
+                     "\"lanczos\": %ld}",
+                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_rowgather, c->n_allreduce, c->n_lanczos);
+    RAILS_REQUIRE(n > 0 && n < cap, "rails_ctx_stats: buffer too small");
+    return RAILS_OK;
+}
+
 extern "C" void *rails_ctx_stream(rails_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 extern "C" int rails_ctx_set_seed(rails_ctx *c, uint64_t seed, uint64_t first_stream)
@@ -112,6 +123,7 @@ int rails_allreduce_dev(rails_ctx *c, double *dev, size_t n)
         rails_set_error("row-partitioned run (nranks=%d) without an all-reduce hook", c->nranks);
         return RAILS_ECOMM;
     }
+    c->n_allreduce++;
     int rc = c->allreduce(c->allreduce_user, dev, n, (void *)c->stream);
     if (rc != 0) {
         rails_set_error("all-reduce hook failed with code %d", rc);

@@ -70,6 +70,7 @@ struct LzArgs {
     const double *B;
     int ldb;
     int k, p;
+    int av_room, mv_room, b_room; // doubles readable from the window start to the end of the padded row
     int64_t m, mpad;
     double *Qc;
     int step;             // -1 = init pass (r := raw q_0)
@@ -110,9 +111,23 @@ __global__ __launch_bounds__(256) void k_lanczos_pass(LzArgs a)
         gmv[c].y = (!init && ok1[c]) ? a.coef[a.k + col + 1] : 0.0;
     }
     const bool bok0 = 2 * lane < a.p, bok1 = 2 * lane + 1 < a.p;
-    gb.x = (!init && bok0) ? a.coef[2 * a.k + 2 * lane] : 0.0;
-    gb.y = (!init && bok1) ? a.coef[2 * a.k + 2 * lane + 1] : 0.0;
-
+    // clamped (always valid, 16-B aligned) column offsets for the unconditional loads: lanes past the last column pair
+    // re-read that pair (same cache line as their neighbour: no extra HBM traffic), never the padding beyond it
+    int cav_off[NCH], cmv_off[NCH];
+    {
+        const int klast = a.k > 1 ? ((a.k - 1) & ~1) : 0;
+        const int lim_av = klast < a.av_room - 2 ? klast : a.av_room - 2;
+        const int lim_mv = klast < a.mv_room - 2 ? klast : a.mv_room - 2;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = 2 * (lane + 64 * c);
+            cav_off[c] = col < lim_av ? col : lim_av;
+            cmv_off[c] = col < lim_mv ? col : lim_mv;
+        }
+    }
+    const int plast = a.p > 1 ? ((a.p - 1) & ~1) : 0;
+    const int lim_b = plast < a.b_room - 2 ? plast : a.b_room - 2;
+    const int cb_off = 2 * lane < lim_b ? 2 * lane : lim_b;
     v2f64 cav[NCH], cmv[NCH], cb;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -138,31 +153,33 @@ __global__ __launch_bounds__(256) void k_lanczos_pass(LzArgs a)
         // U rows per trip of the loop: their 2*NCH+1 row loads are all issued before the first reduction, the
         // U wave reductions are independent chains (rows are independent of each other)
         for (int j0 = 0; j0 < nrows; j0 += U) {
+            // all row loads are UNCONDITIONAL (clamped row / column, values masked afterwards with selects): a load
+            // under a lane-dependent branch makes hipcc wait vmcnt(0) at the join and serialises the loads
             v2f64 xav[U][NCH], xmv[U][NCH], xb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool rok = (j0 + u) < nrows;
-                const int64_t row = row0 + j0 + (rok ? u : 0);
-                const double *pav = a.AV + row * a.ldav + 2 * lane;
-                const double *pmv = a.MV + row * a.ldmv + 2 * lane;
+                const int jr = (j0 + u) < nrows ? (j0 + u) : (nrows - 1);
+                const int64_t row = row0 + jr;
+                const double *pav = a.AV + row * a.ldav;
+                const double *pmv = a.MV + row * a.ldmv;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    xav[u][c] = (v2f64){0.0, 0.0};
-                    xmv[u][c] = (v2f64){0.0, 0.0};
-                    if (ok0[c] && rok) {
-                        xav[u][c] = *reinterpret_cast<const v2f64 *>(pav + 128 * c);
-                        xmv[u][c] = *reinterpret_cast<const v2f64 *>(pmv + 128 * c);
-                        if (!ok1[c]) {
-                            xav[u][c].y = 0.0;
-                            xmv[u][c].y = 0.0;
-                        }
-                    }
+                    xav[u][c] = *reinterpret_cast<const v2f64 *>(pav + cav_off[c]);
+                    xmv[u][c] = *reinterpret_cast<const v2f64 *>(pmv + cmv_off[c]);
                 }
-                xb[u] = (v2f64){0.0, 0.0};
-                if (bok0 && rok) {
-                    xb[u] = *reinterpret_cast<const v2f64 *>(a.B + row * a.ldb + 2 * lane);
-                    if (!bok1) xb[u].y = 0.0;
+                xb[u] = *reinterpret_cast<const v2f64 *>(a.B + row * a.ldb + cb_off);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    xav[u][c].x = ok0[c] ? xav[u][c].x : 0.0;
+                    xav[u][c].y = ok1[c] ? xav[u][c].y : 0.0;
+                    xmv[u][c].x = ok0[c] ? xmv[u][c].x : 0.0;
+                    xmv[u][c].y = ok1[c] ? xmv[u][c].y : 0.0;
                 }
+                xb[u].x = bok0 ? xb[u].x : 0.0;
+                xb[u].y = bok1 ? xb[u].y : 0.0;
             }
             double r[U];
             if (init) {
@@ -511,6 +528,9 @@ extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0
     a.ldb = B->ld;
     a.k = k;
     a.p = p;
+    a.av_room = AV->ld - avc0;
+    a.mv_room = MV->ld - mvc0;
+    a.b_room = B->ld - bc0;
     a.m = m;
     a.mpad = S.mpad;
     a.Qc = S.Qc;
@@ -543,6 +563,7 @@ extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0
         }
     }
     S.steps = steps;
+    c->n_lanczos++;
     *steps_out = steps;
     return RAILS_OK;
 }

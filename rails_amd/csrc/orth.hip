@@ -81,6 +81,7 @@ extern "C" int rails_orthogonalize(rails_ctx *c, rails_panel *V, int k_old, int 
     if (w == 0) return RAILS_OK;
     if (method == 1 || w > 256) {
         if (used) *used = 1;
+        c->n_orth_columnwise++;
         return columnwise(c, V, k_old, k_old + w);
     }
     double *W = V->d + k_old;
@@ -124,6 +125,7 @@ extern "C" int rails_orthogonalize(rails_ctx *c, rails_panel *V, int k_old, int 
                 return RAILS_ELAPACK;
             }
             if (used) *used = 1;
+            c->n_orth_columnwise++;
             return columnwise(c, V, k_old, k_old + w);
         }
         // Rinv (upper triangular): solve R * Rinv = I column by column
@@ -140,5 +142,6 @@ extern "C" int rails_orthogonalize(rails_ctx *c, rails_panel *V, int k_old, int 
         RAILS_TRY(rails_panel_gemm_dev(c, 1.0, W, V->ld, w, c->small, w, 0.0, W, V->ld, V->m)); // in place, row-local
     }
     if (used) *used = 2;
+    c->n_orth_block++;
     return RAILS_OK;
 }

@@ -65,6 +65,8 @@ struct rails_ctx {
     size_t pinned_bytes = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // counters (rails_ctx_stats)
+    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_rowgather = 0, n_allreduce = 0, n_lanczos = 0;
 };
 
 struct rails_panel {
@@ -110,7 +112,8 @@ struct rails_csr {
     int64_t *t_nzptr = nullptr;  // [n_tiles+1] offsets into t_val / t_lcol
     int32_t *t_rp = nullptr;     // [m + n_tiles] per-tile local row offsets (rows+1 per tile)
     double *t_val = nullptr;     // [nnz] values, tile-major
-    int max_fp = 0, max_nz = 0;
+    uint16_t *t_fpos = nullptr;  // LDS row of every footprint entry
+    int max_fp = 0, max_nz = 0, max_pos = 0;
     double tile_reuse = 0.0;
     bool tile_grid = false;
     const char *last_kernel = "";

@@ -239,6 +239,7 @@ extern "C" int rails_csr_destroy(rails_csr *A)
     if (A->t_nzptr) hipFree(A->t_nzptr);
     if (A->t_rp) hipFree(A->t_rp);
     if (A->t_val) hipFree(A->t_val);
+    if (A->t_fpos) hipFree(A->t_fpos);
     delete A;
     return RAILS_OK;
 }
@@ -282,7 +283,7 @@ extern "C" int rails_csr_set_halo(rails_csr *A, int64_t n_send, const int64_t *s
 }
 
 int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool vec2,
-                     bool *done);
+                     int x_room, bool *done);
 
 extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_panel *X, int xc0, int nc, rails_panel *Y, int yc0)
 {
@@ -337,7 +338,8 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     }
     bool done = false;
     const bool vec2 = ((xc0 | yc0) & 1) == 0 && (ldg % 2 == 0);
-    if (A->variant != 1) RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, vec2, &done));
+    if (A->variant != 1) RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, vec2, X->ld - xc0, &done));
+    if (done) c->n_spmm_tiled++;
     if (!done) {
         RAILS_REQUIRE(A->variant != 2, "rails_spmm: LDS-staged kernel requested but not applicable to this operator/shape");
         // Column chunking: with cc columns per launch the window of X rows an XCD gathers from shrinks to
@@ -354,6 +356,7 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
                 RAILS_TRY((dispatch_rg<1>(c, A, Xp + j0, X->ld, xg, ldg, Yp + j0, Y->ld, n)));
         }
         A->last_kernel = "k_spmm_rowgather";
+        c->n_spmm_rowgather++;
     }
     RAILS_HIP_CHECK(hipGetLastError());
     return RAILS_OK;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void k_spmm_tiled(int64_t m, int64_t ntiles, c
                                                     const int32_t *__restrict__ t_rows, const int64_t *__restrict__ t_nzptr,
                                                     const int32_t *__restrict__ t_rp /* per tile-row nz offsets, local to the tile */,
                                                     const double *__restrict__ t_val, const uint16_t *__restrict__ t_lcol,
-                                                    const int32_t *__restrict__ fp_ptr, const int32_t *__restrict__ fp,
+                                                    const int32_t *__restrict__ fp_ptr, const int32_t *__restrict__ fp, const uint16_t *__restrict__ fpos,
                                                     const double *__restrict__ X, int ldx, const double *__restrict__ Xg, int ldg,
                                                     double *__restrict__ Y, int ldy, int nc, int64_t tiles_per_xcd, int nz_cap, int xs_doubles)
 {
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(256) void k_spmm_tiled(int64_t m, int64_t ntiles, c
                 v = *reinterpret_cast<const double2_t *>(src + cidx);
             else if (cidx < nc)
                 v.x = src[cidx];
-            *reinterpret_cast<double2_t *>(&Xs[f * KC + 2 * part]) = v;
+            *reinterpret_cast<double2_t *>(&Xs[(int)fpos[f0 + f] * KC + 2 * part]) = v;
         }
         __syncthreads();
         for (int i = tid / LPR; i < nrows; i += RPP) {
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_pipe(int64_t m, int64_t ntil
                                                          const int32_t *__restrict__ t_rows, const int64_t *__restrict__ t_nzptr,
                                                          const int32_t *__restrict__ t_rp, const double *__restrict__ t_val,
                                                          const uint16_t *__restrict__ t_lcol, const int32_t *__restrict__ fp_ptr,
-                                                         const int32_t *__restrict__ fp, const double *__restrict__ X, int ldx,
+                                                         const int32_t *__restrict__ fp, const uint16_t *__restrict__ fpos, const double *__restrict__ X, int ldx,
                                                          const double *__restrict__ Xg, int ldg, double *__restrict__ Y, int ldy, int nc,
                                                          int64_t tiles_per_xcd, int nz_cap, int xs_doubles)
 {
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_pipe(int64_t m, int64_t ntil
             const int f = idx / LPR;
             const int32_t c = fp[f0 + f];
             srcp[i] = ((c < m) ? (X + (int64_t)c * ldx) : (Xg + ((int64_t)c - m) * ldg)) + 2 * part;
-            dsto[i] = f * KC + 2 * part;
+            dsto[i] = (int)fpos[f0 + f] * KC + 2 * part;
         }
     }
     // D column chunks are in flight in registers; chunk ci is written to LDS buffer (ci & 1) just before it is
@@ -582,6 +585,131 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_pipe(int64_t m, int64_t ntil
 #undef RAILS_LOAD_CHUNK
 }
 
+// Register-resident form: one tile row per slot of KC/2 lanes; the row's (val, footprint index) pairs are loaded
+// into registers once per tile and reused for every column chunk, so the inner loop is ONE ds_read_b128 + 2 FMA per
+// nonzero (the LDS-resident forms above spend three LDS reads per nonzero and are LDS-issue bound).  X chunks are
+// double-buffered in LDS, the next chunk's global loads are in flight during the current chunk's arithmetic.
+template <int KC, int NNZ, int NL>
+__global__ __launch_bounds__(256) void k_spmm_tiled_reg(int64_t m, int64_t ntiles, const int32_t *__restrict__ t_rowptr,
+                                                        const int32_t *__restrict__ t_rows, const int64_t *__restrict__ t_nzptr,
+                                                        const int32_t *__restrict__ t_rp, const double *__restrict__ t_val,
+                                                        const uint16_t *__restrict__ t_lcol, const int32_t *__restrict__ fp_ptr,
+                                                        const int32_t *__restrict__ fp, const uint16_t *__restrict__ fpos, const double *__restrict__ X, int ldx,
+                                                        const double *__restrict__ Xg, int ldg, double *__restrict__ Y, int ldy, int nc,
+                                                        int64_t tiles_per_xcd, int xs_doubles)
+{
+    // Every global load in this kernel is UNCONDITIONAL (clamped indices, duplicate staging slots, full-width chunks
+    // guaranteed by the host): a load under a lane-dependent branch makes hipcc wait vmcnt(0) at the join, which
+    // serialises the staging loads into dependent round trips (measured: 4 us per 14-KB chunk).
+    extern __shared__ double smem[];
+    constexpr int LPR = KC / 2;
+    int64_t t = blockIdx.x;
+    if (tiles_per_xcd > 0) t = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (t >= ntiles) return;
+    const int tr0 = t_rowptr[t];
+    const int nrows = t_rowptr[t + 1] - tr0;
+    const int64_t z0 = t_nzptr[t];
+    const int f0 = fp_ptr[t];
+    const int nf = fp_ptr[t + 1] - f0;
+    const int tid = threadIdx.x;
+    const int part = tid % LPR;
+    const int slot = tid / LPR;
+    const bool has_row = slot < nrows;
+    const int rslot = has_row ? slot : 0; // idle slots shadow row 0 of the tile (never stored)
+
+    // this slot's row: values and LDS offsets of its X rows, padded to NNZ entries with zero coefficients that alias
+    // the row's own first entry (a non-finite value in an unrelated X row can never leak in)
+    double a[NNZ];
+    unsigned xo2[(NNZ + 1) / 2]; // two 16-bit LDS offsets (in doubles) per register: keeps the kernel at <= 128 VGPRs
+    const int p0 = t_rp[tr0 + t + rslot];
+    const int cnt = t_rp[tr0 + t + rslot + 1] - p0;
+    {
+        const int64_t base = z0 + p0;
+        const int last = cnt > 0 ? cnt - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < NNZ; ++u) {
+            const int uu = u < last ? u : last;
+            const double av = t_val[base + uu];
+            const unsigned off = (unsigned)t_lcol[base + uu] * KC + 2 * part;
+            a[u] = (u < cnt) ? av : 0.0;
+            if (u & 1)
+                xo2[u / 2] |= off << 16;
+            else
+                xo2[u / 2] = off;
+        }
+    }
+    const int64_t yrow = (int64_t)t_rows[tr0 + rslot];
+
+    // staging slots: slot indices past the footprint duplicate footprint row 0 (same bytes to the same LDS address).
+    // Sources are kept as 32-bit element offsets (top bit: ghost buffer) and LDS targets as packed 16-bit offsets to
+    // stay within the register budget of 3 waves per SIMD.
+    unsigned soff[NL];
+    unsigned dst2[(NL + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        int idx = tid + 256 * i;
+        int f = idx / LPR;
+        f = f < nf ? f : 0;
+        const int32_t c = fp[f0 + f];
+        const unsigned ghost = (c < m) ? 0u : 0x80000000u;
+        const unsigned eo = ghost ? (unsigned)((int64_t)(c - m) * ldg) : (unsigned)((int64_t)c * ldx);
+        soff[i] = (eo + 2 * part) | ghost;
+        const unsigned d = (unsigned)fpos[f0 + f] * KC + 2 * part;
+        if (i & 1)
+            dst2[i / 2] |= d << 16;
+        else
+            dst2[i / 2] = d;
+    }
+#define RAILS_SRC(i) (((soff[i] & 0x80000000u) ? Xg : X) + (soff[i] & 0x7fffffffu))
+#define RAILS_DST(i) (((i)&1) ? (dst2[(i) / 2] >> 16) : (dst2[(i) / 2] & 0xffffu))
+    // Two column chunks are in flight in registers per thread (Little's law: with one chunk in flight the kernel is bound
+    // by bytes-in-flight x latency, ~41 KB per CU); chunk ci goes to LDS buffer (ci & 1) right before use and its
+    // register set is refilled with chunk ci + 2.  Loads past the last chunk are clamped to it (unused).
+    double2_t stage0[NL], stage1[NL];
+    const int nchunks = (nc + KC - 1) / KC;
+    const int lastc = (nchunks - 1) * KC;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) stage0[i] = *reinterpret_cast<const double2_t *>(RAILS_SRC(i));
+    {
+        const int c1 = KC < lastc ? KC : lastc;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) stage1[i] = *reinterpret_cast<const double2_t *>(RAILS_SRC(i) + c1);
+    }
+#define RAILS_TILE_STEP(STAGE, CI)                                                                      \
+    do {                                                                                                \
+        const int ci__ = (CI);                                                                          \
+        double *Xs = smem + (size_t)(ci__ & 1) * xs_doubles;                                            \
+        _Pragma("unroll") for (int i = 0; i < NL; ++i) *reinterpret_cast<double2_t *>(&Xs[RAILS_DST(i)]) = STAGE[i]; \
+        const int cn__ = (ci__ + 2) * KC < lastc ? (ci__ + 2) * KC : lastc;                             \
+        _Pragma("unroll") for (int i = 0; i < NL; ++i) STAGE[i] = *reinterpret_cast<const double2_t *>(RAILS_SRC(i) + cn__); \
+        __syncthreads();                                                                                \
+        double2_t acc = (double2_t){0.0, 0.0};                                                          \
+        _Pragma("unroll") for (int u = 0; u < NNZ; ++u)                                                 \
+        {                                                                                               \
+            const unsigned off = (u & 1) ? (xo2[u / 2] >> 16) : (xo2[u / 2] & 0xffffu);                 \
+            const double2_t x = *reinterpret_cast<const double2_t *>(&Xs[off]);                         \
+            acc.x = __builtin_fma(a[u], x.x, acc.x);                                                    \
+            acc.y = __builtin_fma(a[u], x.y, acc.y);                                                    \
+        }                                                                                               \
+        const int cidx = ci__ * KC + 2 * part;                                                          \
+        if (cnt == 0) acc = (double2_t){0.0, 0.0};                                                      \
+        if (has_row) {                                                                                  \
+            double *dst = Y + yrow * ldy + cidx;                                                        \
+            if (cidx + 1 < nc)                                                                          \
+                *reinterpret_cast<double2_t *>(dst) = acc;                                              \
+            else if (cidx < nc)                                                                         \
+                *dst = acc.x;                                                                           \
+        }                                                                                               \
+    } while (0)
+    for (int ci = 0; ci < nchunks; ci += 2) {
+        RAILS_TILE_STEP(stage0, ci);
+        if (ci + 1 < nchunks) RAILS_TILE_STEP(stage1, ci + 1);
+    }
+#undef RAILS_TILE_STEP
+#undef RAILS_SRC
+#undef RAILS_DST
+}
+
 // Structured-grid detection from the column offsets of local columns: returns true and (nx, ny, nz) when every
 // sampled offset decomposes as dx + nx*dy + nx*ny*dz with |dx|,|dy|,|dz| <= 1.
 bool detect_grid(const rails_csr *A, int64_t *nx, int64_t *ny, int64_t *nz)
@@ -629,8 +757,16 @@ bool detect_grid(const rails_csr *A, int64_t *nx, int64_t *ny, int64_t *nz)
     return true;
 }
 
+struct GridInfo {
+    bool valid = false;
+    int64_t gx = 0, gy = 0, gz = 0;
+    int bx = 0, by = 0, bz = 0;
+};
+
 struct TilePlan {
     std::vector<int32_t> t_rowptr, t_rows, t_rp, fp_ptr, fp;
+    std::vector<uint16_t> fp_pos; // LDS row of every footprint entry
+    int max_pos = 0;
     std::vector<int64_t> t_nzptr;
     std::vector<double> t_val;
     std::vector<uint16_t> t_lcol;
@@ -639,7 +775,7 @@ struct TilePlan {
 };
 
 // tile_of_row -> plan; returns false when a tile exceeds the caps
-bool make_plan(const rails_csr *A, const std::vector<int32_t> &tile_of_row, int64_t ntiles, int fp_cap, int nz_cap, TilePlan &P)
+bool make_plan(const rails_csr *A, const std::vector<int32_t> &tile_of_row, int64_t ntiles, int fp_cap, int nz_cap, const GridInfo &G, TilePlan &P)
 {
     const int64_t m = A->m;
     P.t_rowptr.assign(ntiles + 1, 0);
@@ -670,13 +806,44 @@ bool make_plan(const rails_csr *A, const std::vector<int32_t> &tile_of_row, int6
         std::sort(tmp.begin(), tmp.end());
         tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
         if ((int)tmp.size() > fp_cap || nzt > nz_cap) return false;
+        // LDS row of every footprint entry.  Box tiles: position inside the halo box with the x extent padded to a
+        // multiple of 4 rows, so the four row slots a ds_read_b128 lane group serves (x-consecutive rows) hit four
+        // different bank quarters; ghost columns and non-grid tiles: consecutive positions.
+        std::vector<uint16_t> pos(tmp.size());
+        int npos = (int)tmp.size();
+        if (G.valid && r1 > r0) {
+            const int64_t rr = P.t_rows[r0];
+            const int64_t ox = (rr % G.gx) / G.bx * G.bx, oy = ((rr / G.gx) % G.gy) / G.by * G.by, oz = (rr / (G.gx * G.gy)) / G.bz * G.bz;
+            const int W = (G.bx + 2 + 3) / 4 * 4, H = G.by + 2;
+            const int box = W * H * (G.bz + 2);
+            int extra = 0;
+            bool ok = true;
+            for (size_t f = 0; f < tmp.size(); ++f) {
+                int64_t c = tmp[f];
+                if (c < m) {
+                    int64_t fx = c % G.gx - ox + 1, fy = (c / G.gx) % G.gy - oy + 1, fz = c / (G.gx * G.gy) - oz + 1;
+                    if (fx < 0 || fx >= W || fy < 0 || fy >= H || fz < 0 || fz >= G.bz + 2) {
+                        ok = false;
+                        break;
+                    }
+                    pos[f] = (uint16_t)(fx + W * (fy + H * fz));
+                } else
+                    pos[f] = (uint16_t)(box + extra++);
+            }
+            if (ok)
+                npos = box + extra;
+            else
+                for (size_t f = 0; f < tmp.size(); ++f) pos[f] = (uint16_t)f;
+        } else
+            for (size_t f = 0; f < tmp.size(); ++f) pos[f] = (uint16_t)f;
+        if (npos > 65535) return false;
         int loc = 0;
         for (int i = r0; i < r1; ++i) {
             int64_t r = P.t_rows[i];
             P.t_rp[(size_t)r0 + t + (i - r0)] = loc;
             for (int64_t p = A->h_rowptr[r]; p < A->h_rowptr[r + 1]; ++p) {
                 P.t_val[z + loc] = A->h_val[p];
-                P.t_lcol[z + loc] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), A->h_col[p]) - tmp.begin());
+                P.t_lcol[z + loc] = pos[std::lower_bound(tmp.begin(), tmp.end(), A->h_col[p]) - tmp.begin()];
                 loc++;
             }
         }
@@ -684,6 +851,8 @@ bool make_plan(const rails_csr *A, const std::vector<int32_t> &tile_of_row, int6
         z += nzt;
         P.t_nzptr[t + 1] = z;
         P.fp.insert(P.fp.end(), tmp.begin(), tmp.end());
+        P.fp_pos.insert(P.fp_pos.end(), pos.begin(), pos.end());
+        P.max_pos = std::max(P.max_pos, npos);
         P.fp_ptr[t + 1] = (int32_t)P.fp.size();
         P.max_fp = std::max(P.max_fp, (int)tmp.size());
         P.max_nz = std::max(P.max_nz, nzt);
@@ -705,11 +874,11 @@ int upload(T **dst, const std::vector<T> &src)
 } // namespace
 
 int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool vec2,
-                     bool *done)
+                     int x_room, bool *done)
 {
     *done = false;
     if (!vec2 || nc < 8 || A->nnz == 0 || A->m >= 0x7fffffffLL) return RAILS_OK;
-    static const int env_rows = spmm_env("RAILS_SPMM_TILE_ROWS", 128);
+    static const int env_rows = spmm_env("RAILS_SPMM_TILE_ROWS", 64);
     static const int env_kc = spmm_env("RAILS_SPMM_TILE_KC", 8);
     static const int env_box = spmm_env("RAILS_SPMM_TILE_BOX", 1);
     const int KC = (env_kc == 16) ? 16 : 8;
@@ -722,6 +891,7 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
         int64_t ntiles = 0;
         int64_t gx = 0, gy = 0, gz = 0;
         bool grid = env_box && detect_grid(A, &gx, &gy, &gz);
+        GridInfo G;
         if (grid) {
             // box of about env_rows grid points: x longest (contiguous in memory), then y, then z
             int bx = 8, by = 4, bz = 4;
@@ -730,21 +900,69 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
             if (gz == 1) { bz = 1; by = std::max(1, env_rows / bx); }
             int64_t tx = (gx + bx - 1) / bx, ty = (gy + by - 1) / by, tz = (gz + bz - 1) / bz;
             ntiles = tx * ty * tz;
+            G.valid = true;
+            G.gx = gx;
+            G.gy = gy;
+            G.gz = gz;
+            G.bx = bx;
+            G.by = by;
+            G.bz = bz;
+            // tiles are numbered along a Morton (Z-order) curve over their (x, y, z) box coordinates: tiles that share
+            // halo rows are processed close together in time (and, with the XCD-aware block map, on the same XCD), so
+            // the halo re-reads are served by L2 / Infinity Cache instead of HBM
+            static const int env_morton = spmm_env("RAILS_SPMM_TILE_MORTON", 1);
+            std::vector<int32_t> rank(ntiles);
+            {
+                std::vector<std::pair<uint64_t, int32_t>> keys(ntiles);
+                auto spread = [](uint64_t v) { // 21 bits -> every third bit
+                    v &= 0x1fffff;
+                    v = (v | v << 32) & 0x1f00000000ffffull;
+                    v = (v | v << 16) & 0x1f0000ff0000ffull;
+                    v = (v | v << 8) & 0x100f00f00f00f00full;
+                    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+                    v = (v | v << 2) & 0x1249249249249249ull;
+                    return v;
+                };
+                for (int64_t z = 0; z < tz; ++z)
+                    for (int64_t y = 0; y < ty; ++y)
+                        for (int64_t x = 0; x < tx; ++x) {
+                            int64_t id = z * ty * tx + y * tx + x;
+                            uint64_t key = env_morton ? (spread(x) | spread(y) << 1 | spread(z) << 2) : (uint64_t)id;
+                            keys[id] = std::make_pair(key, (int32_t)id);
+                        }
+                std::sort(keys.begin(), keys.end());
+                for (int64_t i = 0; i < ntiles; ++i) rank[keys[i].second] = (int32_t)i;
+            }
             for (int64_t r = 0; r < m; ++r) {
                 int64_t x = r % gx, y = (r / gx) % gy, z = r / (gx * gy);
-                tile_of_row[r] = (int32_t)((z / bz) * ty * tx + (y / by) * tx + (x / bx));
+                tile_of_row[r] = rank[(z / bz) * ty * tx + (y / by) * tx + (x / bx)];
             }
         } else {
             int rows = std::min(env_rows, 256);
             ntiles = (m + rows - 1) / rows;
+            // cheap pre-check on a sample of tiles before the full analysis: is a staged row used ~twice or more?
+            {
+                std::vector<int32_t> tmp;
+                double snz = 0, sfp = 0;
+                int64_t step = std::max<int64_t>(1, ntiles / 64);
+                for (int64_t tt = 0; tt < ntiles; tt += step) {
+                    int64_t r0 = tt * rows, r1 = std::min<int64_t>(m, r0 + rows);
+                    tmp.assign(A->h_col.begin() + A->h_rowptr[r0], A->h_col.begin() + A->h_rowptr[r1]);
+                    snz += (double)tmp.size();
+                    std::sort(tmp.begin(), tmp.end());
+                    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                    sfp += (double)tmp.size();
+                }
+                if (sfp <= 0 || snz / sfp < 1.8) return RAILS_OK;
+            }
             for (int64_t r = 0; r < m; ++r) tile_of_row[r] = (int32_t)(r / rows);
         }
         // caps from the LDS budget: vals 8 B + lcol 2 B per nonzero, KC*8 B per footprint row, 1 KiB of row offsets
         TilePlan P;
         int nz_cap = 256 * std::max(1, A->max_row_nnz);
         int fp_cap = 65535;
-        if (make_plan(A, tile_of_row, ntiles, fp_cap, nz_cap, P)) {
-            size_t need = (size_t)((P.max_nz + 3) / 4 * 4) * 8 + (size_t)P.max_fp * KC * 8 + 264 * 4 + (size_t)((P.max_nz + 3) / 4 * 4) * 2 + 64;
+        if (make_plan(A, tile_of_row, ntiles, fp_cap, nz_cap, G, P)) {
+            size_t need = (size_t)((P.max_nz + 3) / 4 * 4) * 8 + (size_t)P.max_pos * KC * 8 + 264 * 4 + (size_t)((P.max_nz + 3) / 4 * 4) * 2 + 64;
             if (P.reuse >= 1.8 && need <= (size_t)lds_budget) {
                 RAILS_TRY(upload(&A->t_rowptr, P.t_rowptr));
                 RAILS_TRY(upload(&A->t_rows, P.t_rows));
@@ -754,6 +972,8 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
                 RAILS_TRY(upload(&A->t_lcol, P.t_lcol));
                 RAILS_TRY(upload(&A->t_fp_ptr, P.fp_ptr));
                 RAILS_TRY(upload(&A->t_fp, P.fp));
+                RAILS_TRY(upload(&A->t_fpos, P.fp_pos));
+                A->max_pos = P.max_pos;
                 A->n_tiles = ntiles;
                 A->max_fp = P.max_fp;
                 A->max_nz = (P.max_nz + 3) / 4 * 4;
@@ -765,7 +985,7 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
         }
     }
     if (!A->tiled_ok) return RAILS_OK;
-    const int xs_doubles = A->max_fp * KC;
+    const int xs_doubles = A->max_pos * KC;
     size_t lds = (size_t)A->max_nz * 8 + (size_t)xs_doubles * 8 + 264 * 4 + (size_t)A->max_nz * 2 + 64;
     int64_t grid = A->n_tiles, tpx = 0;
     static const int xcd_aware = spmm_env("RAILS_SPMM_XCD", 1);
@@ -773,12 +993,53 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
         tpx = (grid + 7) / 8;
         grid = tpx * 8;
     }
+    static const int env_reg = spmm_env("RAILS_SPMM_TILE_REG", 1);
+    // the register-resident kernel reads whole KC-column chunks unconditionally: the padded row must have room for the
+    // rounded-up last chunk, and ghost rows (stored with ld = nc) must be a whole number of chunks
+    const bool full_width_ok = ((nc + KC - 1) / KC * KC <= x_room) && (A->n_ghost == 0 || nc % KC == 0);
+    {
+        const int lpr_r = KC / 2;
+        const int need_nl_r = (A->max_fp * lpr_r + 255) / 256;
+        const size_t lds_reg = 2 * (size_t)xs_doubles * 8;
+        if (env_reg && full_width_ok && xs_doubles < 65536 && (int64_t)A->m * ldx < 0x7fffffffLL && (int64_t)(A->n_ghost + 1) * ldg < 0x7fffffffLL && A->tile_rows <= 256 / lpr_r && A->max_row_nnz <= 32 && need_nl_r <= 8 && lds_reg <= (size_t)lds_budget) {
+            const int nnz4 = (A->max_row_nnz + 3) / 4;
+#define RAILS_REG_ARGS A->m, A->n_tiles, A->t_rowptr, A->t_rows, A->t_nzptr, A->t_rp, A->t_val, A->t_lcol, A->t_fp_ptr, A->t_fp, A->t_fpos, X, ldx, Xg, ldg, Y, ldy, nc, tpx, xs_doubles
+#define RAILS_LAUNCH_REG(KCV, NNZV, NLV)                                                                                              \
+    do {                                                                                                                               \
+        RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled_reg<KCV, NNZV, NLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg)); \
+        hipLaunchKernelGGL((k_spmm_tiled_reg<KCV, NNZV, NLV>), dim3((unsigned)grid), dim3(256), lds_reg, c->stream, RAILS_REG_ARGS); \
+    } while (0)
+#define RAILS_REG_NL(KCV, NNZV)                                  \
+    do {                                                         \
+        if (need_nl_r <= 4) RAILS_LAUNCH_REG(KCV, NNZV, 4);      \
+        else RAILS_LAUNCH_REG(KCV, NNZV, 8);                     \
+    } while (0)
+#define RAILS_REG_NNZ(KCV)                                       \
+    do {                                                         \
+        if (nnz4 <= 2) RAILS_REG_NL(KCV, 8);                     \
+        else if (nnz4 <= 4) RAILS_REG_NL(KCV, 16);               \
+        else if (nnz4 <= 7) RAILS_REG_NL(KCV, 28);               \
+        else RAILS_REG_NL(KCV, 32);                              \
+    } while (0)
+            if (KC == 8)
+                RAILS_REG_NNZ(8);
+            else
+                RAILS_REG_NNZ(16);
+#undef RAILS_REG_NNZ
+#undef RAILS_REG_NL
+#undef RAILS_LAUNCH_REG
+#undef RAILS_REG_ARGS
+            A->last_kernel = "k_spmm_tiled_reg";
+            *done = true;
+            return RAILS_OK;
+        }
+    }
     static const int env_pipe = spmm_env("RAILS_SPMM_TILE_PIPE", 1);
     const int lpr = KC / 2;
     const int need_nl = (A->max_fp * lpr + 255) / 256;
     size_t lds_pipe = lds + (size_t)xs_doubles * 8;
     bool pipe = env_pipe && need_nl <= 8 && lds_pipe <= (size_t)lds_budget;
-#define RAILS_TILED_ARGS A->m, A->n_tiles, A->t_rowptr, A->t_rows, A->t_nzptr, A->t_rp, A->t_val, A->t_lcol, A->t_fp_ptr, A->t_fp, X, ldx, Xg, ldg, Y, ldy, nc, tpx, A->max_nz, xs_doubles
+#define RAILS_TILED_ARGS A->m, A->n_tiles, A->t_rowptr, A->t_rows, A->t_nzptr, A->t_rp, A->t_val, A->t_lcol, A->t_fp_ptr, A->t_fp, A->t_fpos, X, ldx, Xg, ldg, Y, ldy, nc, tpx, A->max_nz, xs_doubles
 #define RAILS_LAUNCH_PIPE(KCV, NLV)                                                                                                    \
     do {                                                                                                                               \
         RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled_pipe<KCV, NLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)); \

@@ -65,6 +65,12 @@ class Context:
     def stream(self):
         return self.lib.rails_ctx_stream(self.h)
 
+    def stats(self):
+        import json
+        buf = C.create_string_buffer(1024)
+        check(self.lib.rails_ctx_stats(self.h, buf, 1024), "rails_ctx_stats")
+        return json.loads(buf.value.decode())
+
     def timer_start(self):
         check(self.lib.rails_timer_start(self.h), "rails_timer_start")
 
