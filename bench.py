@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=125000, help="rows of the bounded CPU sample")
     ap.add_argument("--spmm-variant", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--force-hooks", action="store_true", help="single rank: still route every reduction through torch.distributed (RCCL, world size 1)")
     ap.add_argument("--spmm-only", action="store_true", help="kernel experiment: only the A*X timing, for several column counts")
     ap.add_argument("--spmm-cols", default="128", help="comma list of column counts for --spmm-only")
     args = ap.parse_args()
@@ -100,10 +101,14 @@ def main():
     nranks = world
     torch.cuda.set_device(local_rank)
     dist = None
-    if nranks > 1:
+    if nranks > 1 or args.force_hooks:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if nranks == 1:
+            os.environ.setdefault("MASTER_PORT", "29571")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import rails_amd
@@ -130,6 +135,8 @@ def main():
     else:
         A = rails_amd.HipOperatorWrapper(ctx, rowptr, colg.astype(np.int32), val)
         halo_rows = 0
+        if args.force_hooks:
+            ctx.set_allreduce(partition.make_allreduce(on_device=True))
     A.set_variant(args.spmm_variant)
     nnz_local = int(rowptr[-1])
     log("[rank %d] setup %.1fs: %s, m_local=%d nnz=%d ghosts=%d" % (rank, time.time() - t_setup, desc, ml, nnz_local, halo_rows))

@@ -128,6 +128,8 @@ __global__ __launch_bounds__(256) void k_lanczos_pass(LzArgs a)
     const int plast = a.p > 1 ? ((a.p - 1) & ~1) : 0;
     const int lim_b = plast < a.b_room - 2 ? plast : a.b_room - 2;
     const int cb_off = 2 * lane < lim_b ? 2 * lane : lim_b;
+    gb.x = (!init && bok0) ? a.coef[2 * a.k + 2 * lane] : 0.0;
+    gb.y = (!init && bok1) ? a.coef[2 * a.k + 2 * lane + 1] : 0.0;
     v2f64 cav[NCH], cmv[NCH], cb;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {

@@ -49,22 +49,51 @@ int column_norm(rails_ctx *c, const rails_panel *V, int col, double *nrm)
     return RAILS_OK;
 }
 
+// one pass "v -= P (P^T v)" of column i against the columns [c0, c1) of V
+int project_column(rails_ctx *c, rails_panel *V, int i, int c0, int c1)
+{
+    const int n = c1 - c0;
+    if (n <= 0) return RAILS_OK;
+    RAILS_TRY(rails_small_reserve(c, (size_t)n * sizeof(double)));
+    RAILS_TRY(rails_gram_dev(c, V->d + c0, V->ld, V->d + i, V->ld, V->m, n, 1, c->small));
+    RAILS_TRY(rails_allreduce_dev(c, c->small, (size_t)n));
+    return rails_panel_gemm_dev(c, -1.0, V->d + c0, V->ld, n, c->small, 1, 1.0, V->d + i, V->ld, V->m);
+}
+
+// The reference's recurrence (src/StlWrapper.cpp:308-319) for columns [from, to): normalise, twice subtract the
+// projection on ALL previous columns, normalise.
 int columnwise(rails_ctx *c, rails_panel *V, int from, int to)
 {
     for (int i = from; i < to; ++i) {
         double nrm = 0.0;
         RAILS_TRY(column_norm(c, V, i, &nrm));
         RAILS_TRY(rails_panel_scale(c, V, i, 1, 1.0 / nrm));
-        if (i) {
-            RAILS_TRY(rails_small_reserve(c, (size_t)i * sizeof(double)));
-            for (int pass = 0; pass < 2; ++pass) {
-                RAILS_TRY(rails_gram_dev(c, V->d, V->ld, V->d + i, V->ld, V->m, i, 1, c->small));
-                RAILS_TRY(rails_allreduce_dev(c, c->small, (size_t)i));
-                RAILS_TRY(rails_panel_gemm_dev(c, -1.0, V->d, V->ld, i, c->small, 1, 1.0, V->d + i, V->ld, V->m));
-            }
-        }
+        for (int pass = 0; pass < 2; ++pass) RAILS_TRY(project_column(c, V, i, 0, i));
         RAILS_TRY(column_norm(c, V, i, &nrm));
         RAILS_TRY(rails_panel_scale(c, V, i, 1, 1.0 / nrm));
+    }
+    return RAILS_OK;
+}
+
+// Fallback after the block projection against the old columns has already been applied to all new columns:
+// Gram-Schmidt column by column INSIDE the block (m x w traffic only).  A column that loses more than 5 digits in
+// that step is numerically in the span of its predecessors; it gets the reference's full treatment (normalise,
+// project twice on all previous columns including the old ones, normalise), which is what the reference would have
+// made of it.
+int columnwise_in_block(rails_ctx *c, rails_panel *V, int k_old, int w)
+{
+    for (int i = k_old; i < k_old + w; ++i) {
+        double n0 = 0.0, n1 = 0.0;
+        RAILS_TRY(column_norm(c, V, i, &n0));
+        if (n0 > 0.0) RAILS_TRY(rails_panel_scale(c, V, i, 1, 1.0 / n0));
+        for (int pass = 0; pass < 2; ++pass) RAILS_TRY(project_column(c, V, i, k_old, i));
+        RAILS_TRY(column_norm(c, V, i, &n1));
+        if (!(n1 > 1e-5)) { // the column was normalised before the projection: n1 is the fraction that survived
+            RAILS_TRY(rails_panel_scale(c, V, i, 1, 1.0 / n1));
+            for (int pass = 0; pass < 2; ++pass) RAILS_TRY(project_column(c, V, i, 0, i));
+            RAILS_TRY(column_norm(c, V, i, &n1));
+        }
+        RAILS_TRY(rails_panel_scale(c, V, i, 1, 1.0 / n1));
     }
     return RAILS_OK;
 }
@@ -126,7 +155,7 @@ extern "C" int rails_orthogonalize(rails_ctx *c, rails_panel *V, int k_old, int 
             }
             if (used) *used = 1;
             c->n_orth_columnwise++;
-            return columnwise(c, V, k_old, k_old + w);
+            return columnwise_in_block(c, V, k_old, w);
         }
         // Rinv (upper triangular): solve R * Rinv = I column by column
         std::vector<double> Rinv((size_t)w * w, 0.0);
