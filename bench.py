@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--spmm-variant", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--force-hooks", action="store_true", help="single rank: still route every reduction through torch.distributed (RCCL, world size 1)")
+    ap.add_argument("--projected-lanczos", type=int, default=0, help="1: coefficient-space residual Lanczos (rails/HipSolverOps.hpp)")
     ap.add_argument("--spmm-only", action="store_true", help="kernel experiment: only the A*X timing, for several column counts")
     ap.add_argument("--spmm-cols", default="128", help="comma list of column counts for --spmm-only")
     args = ap.parse_args()
@@ -201,6 +202,7 @@ def main():
     assert code == 0
     solver.set_option("verbose", 1 if args.verbose else 0)
     solver.set_option("max_trips", W + K)
+    solver.set_option("projected_lanczos", args.projected_lanczos)
     marks = {}
 
     def on_trip(trip):
@@ -268,7 +270,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: m=%d rows/GPU (global %d), 27 nnz/row %s CSR, B m x %d, Restart size %d, Reduced size %d, "
                                    "Expand size %d, Lanczos iterations %d" % (ml, mg, desc, args.p, args.restart, args.reduced, args.expand, args.lanczos),
                        "parallelism": "row-partition x%d, RCCL all-reduce of projected blocks" % nranks if nranks > 1 else "single GPU",
-                       "spmm_columns": kk},
+                       "spmm_columns": kk, "residual_lanczos": "projected" if args.projected_lanczos else "fused"},
             "roofline": {"bound": "hbm", "kernel": spmm_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms},
             "cpu_baseline": cpu,

@@ -72,6 +72,8 @@ int rails_ctx_stats(rails_ctx *ctx, char *buf, int cap);
  * generator (src/StlWrapper.cpp:414-423) by one that is identical on CPU and GPU
  * and independent of the row partition. */
 int rails_ctx_set_seed(rails_ctx *ctx, uint64_t seed, uint64_t first_stream);
+/* Current generator position (seed, id of the next stream): lets a caller repeat a draw. */
+int rails_ctx_rng_state(rails_ctx *ctx, uint64_t *seed, uint64_t *next_stream);
 
 /* Row partition of this rank: local rows are global rows [row0, row0 + m_local). */
 int rails_ctx_set_partition(rails_ctx *ctx, int rank, int nranks, int64_t row0, int64_t m_global);
@@ -176,6 +178,13 @@ int rails_resid_lanczos(rails_ctx *ctx, const rails_panel *AV, int avc0, const r
                         const double *T_host, int ldt, const rails_panel *B, int bc0, int p, int L,
                         double *H_host, int ldh, int *steps);
 
+/* Start of a residual Lanczos run only: draws the random start vector q0 (one RNG stream, as Q.random() at :374), and
+ * returns sums_host = [AV^T q0 (k) | MV^T q0 (k) | B^T q0 (p) | q0^T q0] (summed over the ranks) in ONE pass over the
+ * panels.  q0 (un-normalised) becomes Lanczos vector 0 for rails_lanczos_vectors.  Used by the projected-space Lanczos
+ * of rails/HipSolverOps.hpp, which carries the recurrence itself in the (2k+p+1)-dimensional coefficient space. */
+int rails_lanczos_start(rails_ctx *ctx, const rails_panel *AV, int avc0, const rails_panel *MV, int mvc0, int k,
+                        const rails_panel *B, int bc0, int p, double *sums_host);
+
 /* Out[:, oc0:oc0+w] = Q * S with Q the Lanczos vectors of the last rails_resid_lanczos and S (steps x w,
  * host column-major, lds).  Replaces `eigenvectors = Q * v` (src/LyapunovSolver.hpp:443); passing only the
  * selected columns of v writes the expansion vectors straight into V's tail (:338-339). */
@@ -206,6 +215,9 @@ void rails_dgemm(char transa, char transb, int m, int n, int k, double alpha, co
                  int ldb, double beta, double *C, int ldc);
 /* Cholesky (generalized projected solve, block orthogonalisation) */
 void rails_dpotrf(char uplo, int n, double *a, int lda, int *info);
+/* Cholesky with complete pivoting of a positive semi-definite matrix (LAPACK dpstrf): P'AP = R'R, stops at the first pivot
+ * <= tol; *rank = pivots taken, piv 0-based (column j of the factor belongs to column piv[j] of A); info 1 = rank < n. */
+void rails_dpstrf(char uplo, int n, double *a, int lda, int *piv, int *rank, double tol, int *info);
 int rails_host_lapack_init(const char *path);
 const char *rails_host_lapack_path(void);
 

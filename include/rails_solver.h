@@ -32,7 +32,8 @@ int rails_solver_destroy(rails_solver *s);
 int rails_solver_set_parameter(rails_solver *s, const char *name, double value);
 int rails_solver_apply_parameters(rails_solver *s, int *code);
 
-/* extensions: "mass" (use M, generalized equation), "verbose", "max_trips" */
+/* extensions: "mass" (use M, generalized equation), "verbose", "max_trips", "projected_lanczos" (M = I only: carry the
+ * residual Lanczos recurrence in coefficient space, see rails/HipSolverOps.hpp) */
 int rails_solver_set_option(rails_solver *s, const char *name, double value);
 /* called at the start of every loop trip with the index of that trip, and once after the last */
 typedef void (*rails_trip_fn)(void *user, int trip);

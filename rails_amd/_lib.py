@@ -29,6 +29,7 @@ SIGNATURES = {
     "rails_ctx_stream": (_vp, [_vp]),
     "rails_ctx_stats": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "rails_ctx_set_seed": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
+    "rails_ctx_rng_state": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rails_ctx_set_partition": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int64, C.c_int64]),
     "rails_ctx_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
     "rails_csr_create": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, _i32p, _dp, C.POINTER(_vp)]),
@@ -58,6 +59,7 @@ SIGNATURES = {
     "rails_orthogonalize": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _ip]),
     "rails_resid_lanczos": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                       _dp, C.c_int, _ip]),
+    "rails_lanczos_start": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _dp]),
     "rails_lanczos_vectors": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _vp, C.c_int]),
     "rails_lanczos_release": (C.c_int, []),
     "rails_timer_start": (C.c_int, [_vp]),
@@ -67,6 +69,7 @@ SIGNATURES = {
     "rails_dsteqr": (None, [C.c_char, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _ip]),
     "rails_dgemm": (None, [C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int]),
     "rails_dpotrf": (None, [C.c_char, C.c_int, _dp, C.c_int, _ip]),
+    "rails_dpstrf": (None, [C.c_char, C.c_int, _dp, C.c_int, _ip, _ip, C.c_double, _ip]),
     "rails_host_lapack_init": (C.c_int, [C.c_char_p]),
     "rails_host_lapack_path": (C.c_char_p, []),
 }

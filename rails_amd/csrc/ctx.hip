@@ -79,13 +79,21 @@ extern "C" int rails_ctx_stats(rails_ctx *c, char *buf, int cap)
     RAILS_REQUIRE(c && buf && cap > 0, "rails_ctx_stats: bad argument");
     int n = snprintf(buf, (size_t)cap,
                      "{\"orth_block\": %ld, \"orth_columnwise\": %ld, \"spmm_tiled\": %ld, \"spmm_rowgather\": %ld, \"allreduce\": %ld, "
-                     "\"lanczos\": %ld}",
-                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_rowgather, c->n_allreduce, c->n_lanczos);
+                     "\"lanczos\": %ld, \"lanczos_start\": %ld}",
+                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_rowgather, c->n_allreduce, c->n_lanczos, c->n_lanczos_start);
     RAILS_REQUIRE(n > 0 && n < cap, "rails_ctx_stats: buffer too small");
     return RAILS_OK;
 }
 
 extern "C" void *rails_ctx_stream(rails_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int rails_ctx_rng_state(rails_ctx *c, uint64_t *seed, uint64_t *next_stream)
+{
+    RAILS_REQUIRE(c && seed && next_stream, "rails_ctx_rng_state: null argument");
+    *seed = c->seed;
+    *next_stream = c->next_stream;
+    return RAILS_OK;
+}
 
 extern "C" int rails_ctx_set_seed(rails_ctx *c, uint64_t seed, uint64_t first_stream)
 {

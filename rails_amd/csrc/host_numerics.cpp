@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -30,6 +31,7 @@ typedef void (*lp_dgees)(const char *, const char *, lp_select2, const int *, do
 typedef void (*lp_dtrsyl)(const char *, const char *, const int *, const int *, const int *, const double *, const int *,
                           const double *, const int *, double *, const int *, double *, int *);
 typedef void (*lp_dpotrf)(const char *, const int *, double *, const int *, int *);
+typedef void (*lp_dpstrf)(const char *, const int *, double *, const int *, int *, int *, const double *, double *, int *);
 typedef void (*lp_dgemm)(const char *, const char *, const int *, const int *, const int *, const double *, const double *,
                          const int *, const double *, const int *, const double *, double *, const int *);
 }
@@ -42,6 +44,7 @@ struct HostLapack {
     lp_dgees dgees = nullptr;
     lp_dtrsyl dtrsyl = nullptr;
     lp_dpotrf dpotrf = nullptr;
+    lp_dpstrf dpstrf = nullptr; // optional
     lp_dgemm dgemm = nullptr;
 } g_lp;
 std::mutex g_lp_mutex;
@@ -70,6 +73,7 @@ bool try_open(const std::string &path)
     L.dtrsyl = (lp_dtrsyl)lookup(h, "dtrsyl_");
     L.dpotrf = (lp_dpotrf)lookup(h, "dpotrf_");
     L.dgemm = (lp_dgemm)lookup(h, "dgemm_");
+    L.dpstrf = (lp_dpstrf)lookup(h, "dpstrf_");
     if (!L.dsyev || !L.dsteqr || !L.dgees || !L.dtrsyl || !L.dpotrf || !L.dgemm) {
         dlclose(h);
         return false;
@@ -172,6 +176,53 @@ extern "C" void rails_dpotrf(char uplo, int n, double *a, int lda, int *info)
         return;
     }
     g_lp.dpotrf(&uplo, &n, a, &lda, info);
+}
+
+// Cholesky with complete pivoting of a positive semi-definite matrix (LAPACK dpstrf): P' A P = R' R, stops at the first
+// pivot <= tol and returns the rank found.  piv is 0-based here.  Falls back to an unblocked outer-product form when the
+// host LAPACK does not export dpstrf.
+extern "C" void rails_dpstrf(char uplo, int n, double *a, int lda, int *piv, int *rank, double tol, int *info)
+{
+    if (rails_host_lapack_init(nullptr) != RAILS_OK) {
+        *info = -100;
+        return;
+    }
+    if (g_lp.dpstrf) {
+        std::vector<double> work((size_t)2 * (n > 0 ? n : 1));
+        g_lp.dpstrf(&uplo, &n, a, &lda, piv, rank, &tol, work.data(), info);
+        for (int i = 0; i < n; ++i) piv[i] -= 1;
+        return;
+    }
+    // upper form: a(i, j), i <= j
+    *info = 0;
+    if (uplo != 'U' && uplo != 'u') {
+        *info = -1;
+        return;
+    }
+    for (int i = 0; i < n; ++i) piv[i] = i;
+    int r = 0;
+    for (; r < n; ++r) {
+        int q = r;
+        for (int j = r + 1; j < n; ++j)
+            if (a[j + (size_t)j * lda] > a[q + (size_t)q * lda]) q = j;
+        if (!(a[q + (size_t)q * lda] > tol)) break;
+        if (q != r) { // symmetric swap of r and q in the upper triangle
+            std::swap(piv[r], piv[q]);
+            std::swap(a[r + (size_t)r * lda], a[q + (size_t)q * lda]);
+            for (int i = 0; i < r; ++i) std::swap(a[i + (size_t)r * lda], a[i + (size_t)q * lda]);
+            for (int j = q + 1; j < n; ++j) std::swap(a[r + (size_t)j * lda], a[q + (size_t)j * lda]);
+            for (int i = r + 1; i < q; ++i) std::swap(a[r + (size_t)i * lda], a[i + (size_t)q * lda]);
+        }
+        double d = std::sqrt(a[r + (size_t)r * lda]);
+        a[r + (size_t)r * lda] = d;
+        for (int j = r + 1; j < n; ++j) a[r + (size_t)j * lda] /= d;
+        for (int j = r + 1; j < n; ++j) {
+            double f = a[r + (size_t)j * lda];
+            for (int i = r + 1; i <= j; ++i) a[i + (size_t)j * lda] -= a[r + (size_t)i * lda] * f;
+        }
+    }
+    *rank = r;
+    *info = r < n ? 1 : 0;
 }
 
 // Continuous-time Lyapunov equation, SB03MD('C','X','N',trans):

@@ -451,18 +451,18 @@ void launch_pass(rails_ctx *c, const LzArgs &a, int nch, int *nblocks_io, bool s
 
 } // namespace
 
-extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0, const rails_panel *MV, int mvc0, int k,
-                                   const double *T_host, int ldt, const rails_panel *B, int bc0, int p, int L, double *H_host,
-                                   int ldh, int *steps_out)
+static int lz_run(rails_ctx *c, const rails_panel *AV, int avc0, const rails_panel *MV, int mvc0, int k, const double *T_host, int ldt,
+                  const rails_panel *B, int bc0, int p, int L, double *H_host, int ldh, int *steps_out, double *start_sums_host)
 {
-    RAILS_REQUIRE(c && AV && MV && B && H_host && steps_out, "rails_resid_lanczos: null argument");
-    RAILS_REQUIRE(k >= 0 && p >= 0 && L >= 1 && ldh >= L + 1, "rails_resid_lanczos: bad sizes k=%d p=%d L=%d ldh=%d", k, p, L, ldh);
+    const bool only_start = (start_sums_host != nullptr);
+    RAILS_REQUIRE(c && AV && MV && B && (only_start || (H_host && steps_out)), "rails_resid_lanczos: null argument");
+    RAILS_REQUIRE(k >= 0 && p >= 0 && L >= 1 && (only_start || ldh >= L + 1), "rails_resid_lanczos: bad sizes k=%d p=%d L=%d ldh=%d", k, p, L, ldh);
     RAILS_REQUIRE(avc0 >= 0 && avc0 + k <= AV->cap && mvc0 >= 0 && mvc0 + k <= MV->cap && bc0 >= 0 && bc0 + p <= B->cap,
                   "rails_resid_lanczos: column windows outside capacity");
     RAILS_REQUIRE(AV->m == MV->m && AV->m == B->m, "rails_resid_lanczos: row mismatch");
     RAILS_REQUIRE(((avc0 | mvc0 | bc0) & 1) == 0, "rails_resid_lanczos: column windows must start at even columns");
     RAILS_REQUIRE(k <= 512 && p <= 128, "rails_resid_lanczos: fused kernel supports k <= 512, p <= 128 (got %d, %d)", k, p);
-    RAILS_REQUIRE(k == 0 || (T_host && ldt >= k), "rails_resid_lanczos: bad T");
+    RAILS_REQUIRE(k == 0 || only_start || (T_host && ldt >= k), "rails_resid_lanczos: bad T");
     const int64_t m = AV->m;
     const int64_t mpad = (m + 63) / 64 * 64;
     rails_lanczos_state &S = g_lz;
@@ -512,8 +512,10 @@ extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0
     RAILS_TRY(rails_ws_reserve(c, (size_t)nblocks * ncoef * sizeof(double)));
     RAILS_TRY(rails_pinned_reserve(c, std::max<size_t>((size_t)k * k, (size_t)(2 * (L + 2) + 8)) * sizeof(double)));
     // T -> device (contiguous k x k)
-    for (int j = 0; j < k; ++j) memcpy(c->pinned + (size_t)j * k, T_host + (size_t)j * ldt, sizeof(double) * k);
-    if (k) RAILS_HIP_CHECK(hipMemcpyAsync(dT, c->pinned, (size_t)k * k * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!only_start) {
+        for (int j = 0; j < k; ++j) memcpy(c->pinned + (size_t)j * k, T_host + (size_t)j * ldt, sizeof(double) * k);
+        if (k) RAILS_HIP_CHECK(hipMemcpyAsync(dT, c->pinned, (size_t)k * k * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     RAILS_HIP_CHECK(hipMemsetAsync(dcoef, 0, (nsmall - (size_t)k * k) * sizeof(double), c->stream));
     // start vector: Q.random() consumes one RNG stream (src/LyapunovSolver.hpp:374)
     {
@@ -539,14 +541,24 @@ extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0
     a.coef = dcoef;
     a.state = dstate;
     a.partial = c->ws;
-    for (int step = -1; step < L; ++step) {
+    for (int step = -1; step < (only_start ? 0 : L); ++step) {
         a.step = step;
         launch_pass(c, a, nch, &nblocks, false);
         hipLaunchKernelGGL(k_lz_reduce, dim3((ncoef + 63) / 64), dim3(1024), 0, c->stream, c->ws, nblocks, ncoef, dsums);
         RAILS_TRY(rails_allreduce_dev(c, dsums, (size_t)ncoef));
+        if (only_start) break;
         hipLaunchKernelGGL(k_lz_small, dim3(1), dim3(1024), 0, c->stream, dsums, dT, k, p, step, dcoef, dstate, dalpha, dbeta);
     }
     RAILS_HIP_CHECK(hipGetLastError());
+    if (only_start) { // [AV^T q0 | MV^T q0 | B^T q0 | q0^T q0], q0 kept (raw) as Lanczos vector 0
+        RAILS_TRY(rails_pinned_reserve(c, (size_t)ncoef * sizeof(double)));
+        RAILS_HIP_CHECK(hipMemcpyAsync(c->pinned, dsums, (size_t)ncoef * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        memcpy(start_sums_host, c->pinned, (size_t)ncoef * sizeof(double));
+        S.steps = 1;
+        c->n_lanczos_start++;
+        return RAILS_OK;
+    }
     // read back state, alphas, betas (contiguous)
     size_t nback = 8 + 2 * (size_t)(L + 2);
     RAILS_HIP_CHECK(hipMemcpyAsync(c->pinned, dstate, nback * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -568,6 +580,20 @@ extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0
     c->n_lanczos++;
     *steps_out = steps;
     return RAILS_OK;
+}
+
+extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0, const rails_panel *MV, int mvc0, int k,
+                                   const double *T_host, int ldt, const rails_panel *B, int bc0, int p, int L, double *H_host,
+                                   int ldh, int *steps_out)
+{
+    return lz_run(c, AV, avc0, MV, mvc0, k, T_host, ldt, B, bc0, p, L, H_host, ldh, steps_out, nullptr);
+}
+
+extern "C" int rails_lanczos_start(rails_ctx *c, const rails_panel *AV, int avc0, const rails_panel *MV, int mvc0, int k,
+                                   const rails_panel *B, int bc0, int p, double *sums_host)
+{
+    RAILS_REQUIRE(sums_host, "rails_lanczos_start: null output");
+    return lz_run(c, AV, avc0, MV, mvc0, k, nullptr, 0, B, bc0, p, 1, nullptr, 0, nullptr, sums_host);
 }
 
 extern "C" int rails_lanczos_vectors(rails_ctx *c, const double *S_host, int lds, int w, rails_panel *Out, int oc0)

@@ -118,6 +118,8 @@ extern "C" int rails_solver_set_option(rails_solver *s, const char *name, double
         s->solver->set_verbose(value != 0.0);
     else if (n == "max_trips")
         s->solver->set_max_trips((int)value);
+    else if (n == "projected_lanczos")
+        s->solver->set_projected_lanczos(value != 0);
     else {
         rails_set_error("rails_solver_set_option: unknown option '%s'", name);
         return RAILS_EINVAL;

@@ -163,12 +163,21 @@ struct SolverOps {
         return AW;
     }
 
-    static int lanczos(SolverT &solver, MultiVector const &AV, MultiVector const &MV, DenseMatrix const &T, int max_iter, Lanczos &out)
+    // per-solve scratch of the backend (nothing for the generic form)
+    struct State {
+    };
+
+    // VAV and BV (the projected operator and B'V) are passed along for backends that can use them; the generic form
+    // is the reference's member sequence and ignores them
+    static int lanczos(SolverT &solver, State &, MultiVector const &AV, MultiVector const &MV, DenseMatrix const &T, DenseMatrix const &,
+                       MultiVector const &, int max_iter, Lanczos &out)
     {
         DenseMatrix H(max_iter + 1, max_iter + 1);
         out.eigenvalues = DenseMatrix(max_iter, 1);
         return solver.resid_lanczos(AV, MV, T, H, out.eigenvectors, out.eigenvalues, max_iter);
     }
+
+    static void on_restart(State &, DenseMatrix const &) {}
 
     // V <- V * X (first X.N() columns), as `V.view(0, X.N()-1) = V * X; V.resize(X.N())`   (:265-266)
     static void multiply_inplace(MultiVector &V, DenseMatrix const &X)
@@ -188,7 +197,7 @@ public:
     Solver(Matrix const &A, MatrixOrMultiVector const &B, Matrix const &M)
         : A_(A), B_(B), M_(M), max_iter_(1000), tol_(1e-3), expand_size_(3), lanczos_iterations_(10), restart_size_(-1), reduced_size_(-1),
           restart_iterations_(20), restart_tolerance_(tol_ * 1e-3), minimize_solution_space_(true), restart_from_solution_(false),
-          use_mass_matrix_(false), verbose_(true), max_trips_(0), trips_(0)
+          use_mass_matrix_(false), verbose_(true), max_trips_(0), trips_(0), projected_lanczos_(false)
     {
     }
 
@@ -220,6 +229,10 @@ public:
     void use_mass_matrix(bool on) { use_mass_matrix_ = on; }
     void set_verbose(bool on) { verbose_ = on; }
     void set_max_trips(int n) { max_trips_ = n; }
+    // extension: residual Lanczos carried in the (2k+p+1)-dimensional coefficient space where the backend supports it
+    void set_projected_lanczos(bool on) { projected_lanczos_ = on; }
+    bool projected_lanczos() const { return projected_lanczos_; }
+    bool mass_matrix_in_use() const { return use_mass_matrix_; }
     void set_trip_callback(std::function<void(int)> cb) { on_trip_ = cb; }
     int trips() const { return trips_; }
     std::vector<double> const &residual_history() const { return res_hist_; }
@@ -234,6 +247,7 @@ public:
         int max_size = std::max(V.N(), std::min(restart_size_ > 0 ? restart_size_ : 100, n));
         trips_ = 0;
         res_hist_.clear();
+        ops_state_ = typename Ops::State();
 
         if (!restart_from_solution_) {
             V.resize(max_size);
@@ -339,7 +353,7 @@ public:
             typename Ops::Lanczos lz; // :211-215
             {
                 ScopedTimer t(&profile_, "Residual Lanczos");
-                Ops::lanczos(*this, AV, use_mass_matrix_ ? MV : V, T, lanczos_iterations_, lz);
+                Ops::lanczos(*this, ops_state_, AV, use_mass_matrix_ ? MV : V, T, VAV, BV, lanczos_iterations_, lz);
             }
 
             double res = lz.eigenvalues.norm_inf(); // :217
@@ -397,6 +411,7 @@ public:
                 VAV.view() = tmp;
 
                 Ops::multiply_inplace(AV, X); // :290-291
+                Ops::on_restart(ops_state_, X);
 
                 tmp = X.transpose() * (VBV * X); // :293-295
                 VBV.resize(X.N(), X.N());
@@ -639,6 +654,8 @@ protected:
     std::vector<double> res_hist_;
     std::function<void(int)> on_trip_;
     std::map<std::string, double> profile_;
+    bool projected_lanczos_;
+    typename Ops::State ops_state_;
 };
 
 } // namespace rails

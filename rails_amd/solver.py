@@ -27,6 +27,7 @@ class Solver:
         self.h = h
         self._cb = None
         self.k = 0
+        ctx._solvers.add(self)
 
     def set_parameters(self, params):
         for name, value in params.items():
@@ -97,7 +98,8 @@ class Solver:
 
     def close(self):
         if self.h:
-            self.lib.rails_solver_destroy(self.h)
+            if self.ctx.h:  # after the context is gone the handle cannot be released safely any more
+                self.lib.rails_solver_destroy(self.h)
             self.h = None
 
     def __del__(self):

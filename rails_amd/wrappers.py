@@ -10,6 +10,7 @@ The C++ header-only wrappers in rails_amd/include/rails/ are the drop-in for the
 templated Solver; these Python classes exist so the parity tests read like the reference's tests.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -39,6 +40,7 @@ class Context:
         check(self.lib.rails_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)), "rails_ctx_create")
         self.h = h
         self._cb = None
+        self._solvers = weakref.WeakSet()  # closed before the context (their C++ side owns panels of this context)
         self.set_seed(seed, first_stream)
 
     def set_seed(self, seed, first_stream=0):
@@ -81,6 +83,8 @@ class Context:
 
     def close(self):
         if self.h:
+            for s in list(self._solvers):
+                s.close()
             self.lib.rails_lanczos_release()
             self.lib.rails_ctx_destroy(self.h)
             self.h = None

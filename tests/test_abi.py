@@ -106,6 +106,25 @@ def test_host_dsyev_and_dsteqr():
     np.testing.assert_allclose(dd, w, atol=1e-13)
 
 
+def test_host_pivoted_cholesky_reveals_rank():
+    # rails_dpstrf (projected-space residual Lanczos, rails/HipSolverOps.hpp): P'SP = R'R on a rank-deficient Gram matrix
+    import rails_amd
+
+    lib = rails_amd.load()
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    rng = np.random.default_rng(3)
+    n, r = 12, 7
+    W = rng.standard_normal((40, r)) @ rng.standard_normal((r, n))
+    S = W.T @ W
+    a = np.asfortranarray(S.copy())
+    piv = np.zeros(n, dtype=np.int32)
+    rank, info = C.c_int(0), C.c_int(0)
+    lib.rails_dpstrf(b"U", n, a.ctypes.data_as(dp), n, piv.ctypes.data_as(ip), C.byref(rank), 1e-10 * S.diagonal().max(), C.byref(info))
+    assert rank.value == r and info.value == 1
+    R = np.triu(a)[:r, :]
+    np.testing.assert_allclose(R.T @ R, S[np.ix_(piv, piv)], atol=1e-9 * S.max())
+
+
 def test_wrappers_instantiate_the_reference_solver_template():
     """Compile-only (no link, no run): the reference's RAILS::Solver template accepts the HIP wrapper classes."""
     import subprocess

@@ -20,7 +20,7 @@ def ctx():
     c.close()
 
 
-def _solve(ctx, A, B, params, seed=1, M=None, V0=None, mass=False):
+def _solve(ctx, A, B, params, seed=1, M=None, V0=None, mass=False, options=None):
     import rails_amd
     from rails_amd import problems as P
 
@@ -33,6 +33,8 @@ def _solve(ctx, A, B, params, seed=1, M=None, V0=None, mass=False):
     s.set_option("verbose", 0)
     if mass:
         s.set_option("mass", 1)
+    for name, value in (options or {}).items():
+        s.set_option(name, value)
     code, V, T = s.solve(V0=V0)
     return code, V, T, s
 
@@ -109,15 +111,15 @@ def test_solver_n20_reference_cases(ctx):
     assert code == 0 and V2.shape[1] < 20 and np.abs(_residual(A, B, V2, T2)).max() < 1e-3
 
 
-def _compare_with_oracle(ctx, oracle, A, B, params, tol, seed, M=None, nhist=6, trajectory=True):
+def _compare_with_oracle(ctx, oracle, A, B, params, tol, seed, M=None, nhist=6, trajectory=True, options=None, first_rtol=1e-9):
     """trajectory=True needs `Lanczos iterations` <= 2 + p: otherwise the first trips run Lanczos past the rank of the
     residual operator and the expansion vectors are rounding-level chaotic in the reference algorithm itself
     (oracle/README.md); then only invariants are compared."""
-    code, V, T, s = _solve(ctx, A, B, params, seed=seed, M=M, mass=M is not None)
+    code, V, T, s = _solve(ctx, A, B, params, seed=seed, M=M, mass=M is not None, options=options)
     out = oracle.solve(A, B, oracle.params({**params, "rng_mode": 1, "seed": seed}), M=M)
     assert code == out["ret"] == 0
     h, ho = s.history(), out["res_hist"]
-    assert abs(h[0] - ho[0]) <= 1e-9 * abs(ho[0])  # first trip: same start vector, same arithmetic up to summation order
+    assert abs(h[0] - ho[0]) <= first_rtol * abs(ho[0])  # first trip: same start vector, same arithmetic up to summation order
     if trajectory:
         assert abs(s.trips() - out["trips"]) <= 1
         n = min(nhist, len(h), len(ho))
@@ -213,3 +215,48 @@ def test_warm_start_continuation(ctx, oracle):
     assert code == 0
     assert s2.trips() < cold_trips
     assert s2.relative_residual() < 1e-3
+
+
+def test_projected_lanczos_matches_oracle(ctx, oracle):
+    # opt-in coefficient-space form of the residual Lanczos (rails/HipSolverOps.hpp): same random start vector, same
+    # recurrence in an orthonormal basis of span[V, AV, B, q0] -> same tridiagonal matrix, same expansion vectors up to
+    # rounding (the Cholesky factor of the Gram matrix of [AV, B] - V V'[AV, B] costs a few digits: 1e-7 on the estimate)
+    from rails_amd import problems as P
+
+    opts = {"projected_lanczos": 1}
+    A = P.dense_stable(256, seed=1)
+    B = P.rhs(256, 8, seed=2)
+    params = {"Restart size": 64, "Reduced size": 32, "Expand size": 4, "Lanczos iterations": 8, "Tolerance": 1e-3}
+    before = ctx.stats()
+    V, T, s, out = _compare_with_oracle(ctx, oracle, A, B, params, 1e-3, seed=1, trajectory=True, options=opts, first_rtol=1e-7)
+    after = ctx.stats()
+    assert after["lanczos_start"] - before["lanczos_start"] >= s.trips() - 2  # the projected form really ran
+    assert np.linalg.norm(_residual(A, B, V, T)) / np.linalg.norm(B @ B.T) < 2e-3
+    Q = V.T @ V
+    assert np.abs(Q - np.eye(Q.shape[0])).max() < 1e-10
+
+    A = P.laplace7(20, 20, 15)
+    m = A[0].size - 1
+    B = P.rhs(m, 8, seed=5)
+    params = {"Restart size": 64, "Reduced size": 32, "Expand size": 8, "Lanczos iterations": 10, "Tolerance": 1e-3}
+    V, T, s, out = _compare_with_oracle(ctx, oracle, A, B, params, 1e-3, seed=3, trajectory=True, options=opts, first_rtol=1e-7)
+    assert s.relative_residual() < 5e-3
+    # odd expand size, Lanczos past the rank of the residual operator: invariants only
+    params = {"Restart size": 32, "Reduced size": 16, "Expand size": 3, "Lanczos iterations": 10, "Tolerance": 1e-3}
+    A = P.dense_stable(256, seed=1)
+    B = P.rhs(256, 4, seed=2)
+    V, T, s, out = _compare_with_oracle(ctx, oracle, A, B, params, 1e-3, seed=1, trajectory=False, options=opts, first_rtol=1e-7)
+    assert np.linalg.norm(_residual(A, B, V, T)) / np.linalg.norm(B @ B.T) < 2e-3
+
+
+def test_projected_lanczos_falls_back_with_mass_matrix(ctx, oracle):
+    from rails_amd import problems as P
+
+    A = P.laplace7(12, 12, 10)
+    m = A[0].size - 1
+    M = P.mass_diag(m, seed=4)
+    B = P.rhs(m, 6, seed=6)
+    params = {"Restart size": 60, "Reduced size": 30, "Expand size": 4, "Lanczos iterations": 8, "Tolerance": 1e-4}
+    before = ctx.stats()
+    _compare_with_oracle(ctx, oracle, A, B, params, 1e-4, seed=9, M=M, options={"projected_lanczos": 1})
+    assert ctx.stats()["lanczos_start"] == before["lanczos_start"]
