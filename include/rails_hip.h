@@ -114,8 +114,9 @@ int rails_csr_set_halo(rails_csr *A, int64_t n_send, const int64_t *send_rows, i
 int rails_spmm(rails_ctx *ctx, rails_csr *A, int trans, const rails_panel *X, int xc0, int nc,
                rails_panel *Y, int yc0);
 
-/* Kernel variant control for benchmarking: 0 = auto, 1 = row-gather kernel,
- * 2 = LDS-staged footprint kernel. */
+/* Kernel variant control for benchmarking and tests: 0 = auto, 1 = row-gather kernel (column chunking by the window
+ * heuristic), 2 = LDS-staged footprint kernel, 3 = row-gather over the whole width, 4 / 5 = row-gather in 32 / 64 column
+ * chunks inside one launch. */
 int rails_csr_set_variant(rails_csr *A, int variant);
 /* name of the kernel the last rails_spmm on A launched */
 const char *rails_csr_last_kernel(const rails_csr *A);

@@ -84,6 +84,7 @@ struct rails_csr {
     int32_t *col = nullptr;
     double *val = nullptr;
     int max_row_nnz = 0;
+    int64_t window_rows = 0; // mean (max col - min col + 1) over a sample of rows: the sliding window of X rows a row block gathers from
     // transposed copy, built lazily
     rails_csr *AT = nullptr;
     // host copy kept for building the transpose / tiling analysis

@@ -138,6 +138,122 @@ int launch_rg(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const 
     return RAILS_OK;
 }
 
+
+// Kernel 1b (row-gather, column chunks inside one launch): for wide X (nc = 128) the sliding window of X rows that the
+// row blocks of one XCD gather from (window_rows x nc x 8 B: 8 MiB for |j-i| <= 4096) does not fit the XCD's 4 MiB L2 and
+// two thirds of the gathers miss it.  Here the panel is cut into chunks of CC = 2*LPR columns and every XCD walks its
+// row range once per chunk (blocks are dealt to the XCDs round-robin and, per XCD, in launch order: chunk-major), so the
+// window is window_rows x CC x 8 B and the gathers hit L2.  LPR lanes own a row (4 rows per wave at CC = 32); the block's
+// (col, val) run is staged in LDS once so that the per-nonzero loads are LDS broadcasts instead of vector-memory loads.
+template <int LPR, int RPG>
+__global__ __launch_bounds__(256) void k_spmm_rowgather_cc(int64_t m, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                           const double *__restrict__ val, const double *__restrict__ X, int ldx,
+                                                           const double *__restrict__ Xg, int ldg, double *__restrict__ Y, int ldy, int nc,
+                                                           int64_t blocks_per_xcd, int lds_cap)
+{
+    constexpr int GROUPS = 256 / LPR;
+    constexpr int ROWS = GROUPS * RPG;
+    constexpr int CC = 2 * LPR;
+    constexpr int U = 8;
+    extern __shared__ double smem[];
+    double *s_val = smem;
+    int32_t *s_col = reinterpret_cast<int32_t *>(smem + lds_cap);
+    const int g = threadIdx.x / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t s = blockIdx.x >> 3;
+    const int chunk = (int)(s / blocks_per_xcd);
+    const int64_t lb = (int64_t)(blockIdx.x & 7) * blocks_per_xcd + (s - (int64_t)chunk * blocks_per_xcd);
+    const int64_t r0 = lb * ROWS;
+    if (r0 >= m) return;
+    const int64_t r1 = (r0 + ROWS < m) ? r0 + ROWS : m;
+    const int64_t nz0 = rowptr[r0], nz1 = rowptr[r1];
+    const bool staged = (nz1 - nz0) <= lds_cap; // block-uniform
+    if (staged) {
+        for (int64_t q = nz0 + threadIdx.x; q < nz1; q += 256) {
+            s_col[q - nz0] = col[q];
+            s_val[q - nz0] = val[q];
+        }
+        __syncthreads();
+    }
+    const int cb = chunk * CC + l * 2;
+    if (cb >= nc) return;
+    const bool full = (cb + 2 <= nc);
+    for (int rr = 0; rr < RPG; ++rr) {
+        const int64_t row = r0 + (int64_t)rr * GROUPS + g; // the 256/LPR rows in flight are consecutive
+        if (row >= m) break;
+        const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
+        double2_t acc = (double2_t){0.0, 0.0};
+        for (int64_t p = p0; p < p1; p += U) {
+            int32_t c[U];
+            double a[U];
+            const int cnt = (int)((p1 - p) < U ? (p1 - p) : U);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = u < cnt;
+                const int64_t q = ok ? p + u : p0;
+                c[u] = staged ? s_col[q - nz0] : col[q];
+                const double av = staged ? s_val[q - nz0] : val[q];
+                a[u] = ok ? av : 0.0;
+            }
+            if (full) {
+                double2_t x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double *src = (c[u] < m) ? (X + (int64_t)c[u] * ldx + cb) : (Xg + ((int64_t)c[u] - m) * ldg + cb);
+                    x[u] = *reinterpret_cast<const double2_t *>(src);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc.x = __builtin_fma(a[u], x[u].x, acc.x);
+                    acc.y = __builtin_fma(a[u], x[u].y, acc.y);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double *src = (c[u] < m) ? (X + (int64_t)c[u] * ldx + cb) : (Xg + ((int64_t)c[u] - m) * ldg + cb);
+                    acc.x = __builtin_fma(a[u], *src, acc.x);
+                }
+            }
+        }
+        double *dst = Y + row * ldy + cb;
+        if (full)
+            *reinterpret_cast<double2_t *>(dst) = acc;
+        else
+            *dst = acc.x;
+    }
+}
+
+template <int LPR>
+int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc)
+{
+    constexpr int GROUPS = 256 / LPR;
+    constexpr int RPG = (LPR >= 32) ? 8 : 4;
+    constexpr int ROWS = GROUPS * RPG; // 64 rows per block
+    constexpr int CC = 2 * LPR;
+    const int nchunks = (nc + CC - 1) / CC;
+    const int64_t blocks = (A->m + ROWS - 1) / ROWS;
+    const int64_t bpx = (blocks + 7) / 8;
+    const int64_t grid = bpx * 8 * nchunks;
+    RAILS_REQUIRE(grid <= 0x7fffffffLL, "rails_spmm: grid too large");
+    const int lds_cap = 2048; // nonzeros of one block staged in LDS (24 KiB); longer runs read (col, val) from global memory
+    hipLaunchKernelGGL((k_spmm_rowgather_cc<LPR, RPG>), dim3((unsigned)grid), dim3(256), (size_t)lds_cap * 12, c->stream, A->m, A->rowptr,
+                       A->col, A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx, lds_cap);
+    return RAILS_OK;
+}
+
+// Columns per chunk for the row-gather kernel; 0 = whole width.  Measured on MI355X at nc = 128 (profiles/r01_spmm_chunked.md):
+// chunking removes the L2 misses as intended (banded |j-i| <= 4096: 18.7 GB -> 3.1 GB of L2 fills per product) but the
+// product does not get faster (2.34 -> 2.6 ms): the 27.6 GB of gathered row segments are bounded by L2 -> L1 throughput
+// (~12 TB/s), not by the fabric.  So auto = whole width; the chunked kernel stays selectable (variants 4/5, RAILS_SPMM_CHUNK).
+int rowgather_chunk(const rails_csr *A, int nc)
+{
+    static const int chunk_env = spmm_env("RAILS_SPMM_CHUNK", 0);
+    if (A->variant == 4 || A->variant == 5) return nc > 32 * (A->variant - 3) ? 32 * (A->variant - 3) : 0;
+    if (A->variant == 3) return 0;
+    if (chunk_env == 32 || chunk_env == 64) return nc > chunk_env ? chunk_env : 0;
+    return 0;
+}
+
 template <int VEC>
 int dispatch_rg(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc)
 {
@@ -197,6 +313,21 @@ extern "C" int rails_csr_create(rails_ctx *c, int64_t m_local, int64_t n_cols_ex
     A->ncols_ext = n_cols_ext;
     A->nnz = nnz;
     A->max_row_nnz = maxrow;
+    {
+        const int64_t stride = std::max<int64_t>(1, m_local / 4096);
+        int64_t sum = 0, cnt = 0;
+        for (int64_t i = 0; i < m_local; i += stride) {
+            if (rowptr[i + 1] == rowptr[i]) continue;
+            int32_t lo = col[rowptr[i]], hi = lo;
+            for (int64_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+                lo = std::min(lo, col[q]);
+                hi = std::max(hi, col[q]);
+            }
+            sum += (int64_t)hi - lo + 1;
+            cnt++;
+        }
+        A->window_rows = cnt ? sum / cnt : 0;
+    }
     A->h_rowptr.assign(rowptr, rowptr + m_local + 1);
     if (nnz) {
         A->h_col.assign(col, col + nnz);
@@ -250,7 +381,7 @@ extern "C" const char *rails_csr_last_kernel(const rails_csr *A) { return A ? A-
 
 extern "C" int rails_csr_set_variant(rails_csr *A, int variant)
 {
-    RAILS_REQUIRE(A && variant >= 0 && variant <= 2, "rails_csr_set_variant: bad argument");
+    RAILS_REQUIRE(A && variant >= 0 && variant <= 5, "rails_csr_set_variant: bad argument");
     A->variant = variant;
     return RAILS_OK;
 }
@@ -338,22 +469,24 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     }
     bool done = false;
     const bool vec2 = ((xc0 | yc0) & 1) == 0 && (ldg % 2 == 0);
-    if (A->variant != 1) RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, vec2, X->ld - xc0, &done));
+    if (A->variant == 0 || A->variant == 2) RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, vec2, X->ld - xc0, &done));
     if (done) c->n_spmm_tiled++;
     if (!done) {
         RAILS_REQUIRE(A->variant != 2, "rails_spmm: LDS-staged kernel requested but not applicable to this operator/shape");
-        // Column chunking: with cc columns per launch the window of X rows an XCD gathers from shrinks to
-        // window_rows * cc * 8 bytes; chunks run back to back so each pass finds its window in L2.
-        static const int chunk_env = spmm_env("RAILS_SPMM_CHUNK", 0);
-        int cc = chunk_env > 0 ? chunk_env : nc;
-        if (cc & 1) cc += 1;
-        for (int j0 = 0; j0 < nc; j0 += cc) {
-            int n = std::min(cc, nc - j0);
-            const double *xg = (Xg == Xp) ? Xp + j0 : Xg + j0;
-            if (vec2)
-                RAILS_TRY((dispatch_rg<2>(c, A, Xp + j0, X->ld, xg, ldg, Yp + j0, Y->ld, n)));
-            else
-                RAILS_TRY((dispatch_rg<1>(c, A, Xp + j0, X->ld, xg, ldg, Yp + j0, Y->ld, n)));
+        const int cc = vec2 ? rowgather_chunk(A, nc) : 0;
+        if (cc == 32)
+            RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
+        else if (cc == 64)
+            RAILS_TRY((launch_rg_cc<32>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
+        else if (vec2)
+            RAILS_TRY((dispatch_rg<2>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
+        else
+            RAILS_TRY((dispatch_rg<1>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
+        if (cc) {
+            A->last_kernel = "k_spmm_rowgather_cc";
+            c->n_spmm_rowgather++;
+            RAILS_HIP_CHECK(hipGetLastError());
+            return RAILS_OK;
         }
         A->last_kernel = "k_spmm_rowgather";
         c->n_spmm_rowgather++;

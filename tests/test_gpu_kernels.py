@@ -137,6 +137,48 @@ def test_spmm_lds_staged_kernel_matches_oracle(ctx, oracle, name):
         opu.apply(MV(ctx, g.uniform(-1, 1, (3001, 16))))
 
 
+@pytest.mark.parametrize("variant", [4, 5])
+def test_spmm_rowgather_column_chunks_match_oracle(ctx, oracle, variant):
+    """variants 4 / 5 = row-gather in 32 / 64 column chunks inside one launch (k_spmm_rowgather_cc): same per-row summation
+    order as the plain row-gather kernel; ragged rows, a row block longer than the LDS staging buffer, odd widths."""
+    import rails_amd
+    from rails_amd import problems as P
+
+    g = np.random.default_rng(17)
+    # ragged: empty rows, rows of 1..300 entries (blocks of 64 rows exceed the 2048-entry LDS buffer -> global (col, val) path)
+    m = 777
+    lens = g.integers(0, 12, m)
+    lens[100:140] = g.integers(100, 300, 40)
+    lens[5] = 0
+    lens[-1] = 0
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = g.integers(0, m, rowptr[-1]).astype(np.int32)
+    val = g.uniform(-1, 1, rowptr[-1])
+    cases = [P.banded_random(5000, 27, 300, seed=1), P.stencil27(9, 8, 7, random_values=True, seed=3), (rowptr, col, val)]
+    for A in cases:
+        mm = A[0].size - 1
+        op = rails_amd.HipOperatorWrapper(ctx, *A)
+        op.set_variant(variant)
+        for nc, xoff, yoff in ((128, 0, 0), (130, 2, 4), (97, 0, 0), (66, 0, 2), (40, 0, 0)):
+            if nc <= 32 * (variant - 3):
+                continue
+            Xh = g.uniform(-1, 1, (mm, nc))
+            big = MV(ctx, m=mm, n=nc + xoff, capacity=nc + xoff)
+            X = big.view(xoff, xoff + nc - 1)
+            X.from_host(Xh)
+            outp = MV(ctx, m=mm, n=nc + yoff, capacity=nc + yoff + 3)
+            Y = outp.view(yoff, yoff + nc - 1)
+            op.apply(X, Y)
+            assert op.last_kernel() == "k_spmm_rowgather_cc"
+            ref = oracle.csr_spmm(*A, Xh)
+            assert np.abs(Y.to_host() - ref).max() <= 1e-14 * np.abs(ref).max() * 40
+            op.set_variant(3)
+            Y3 = op.apply(X)
+            assert op.last_kernel() == "k_spmm_rowgather"
+            assert np.array_equal(Y3.to_host(), Y.to_host())  # identical summation order -> bit-identical
+            op.set_variant(variant)
+
+
 def test_spmm_ragged_and_empty_rows(ctx, oracle):
     import rails_amd
 
