@@ -163,7 +163,8 @@ int rails_panel_gemm(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0
  * equivalent to the reference's column-wise CGS2 with pre/post normalisation
  * (src/StlWrapper.cpp:305-321): block CGS2 + CholQR2 on MFMA, falling back to the column-wise
  * form when the block Gram matrix is numerically rank deficient.  method: 0 = auto,
- * 1 = force column-wise, 2 = force block.  *used (may be NULL) receives the method used. */
+ * 1 = force column-wise, 2 = force block.  *used (may be NULL) receives the method used (1 column-wise, 2 block,
+ * 3 block after one repair round: dependent columns replaced by their normalised residuals, see orth.hip). */
 int rails_orthogonalize(rails_ctx *ctx, rails_panel *V, int k_old, int w, int method, int *used);
 
 /* Fused residual Lanczos (src/LyapunovSolver.hpp:367-447): L steps of Lanczos on the implicit

@@ -15,6 +15,7 @@
 #include "rails_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -98,6 +99,64 @@ int columnwise_in_block(rails_ctx *c, rails_panel *V, int k_old, int w)
     return RAILS_OK;
 }
 
+// Repair step of the block method for a numerically rank-deficient block (typical in RAILS: the Ritz values of the
+// residual operator come in +/- pairs whose vectors coincide once span(V) is projected out, so about every second
+// expansion vector is dependent on its predecessors).  The reference's recurrence turns such a column into the
+// normalised rounding noise of its projection and carries on.  Here: Cholesky of the block Gram matrix G with the
+// dependent pivots skipped (r_ii = 1, row i of R zero): W <- W R^-1 orthonormalises the independent columns among
+// themselves and leaves every dependent column as its (tiny) residual against the independent columns before it; those
+// residuals are scaled to unit norm and the block procedure is run once more on the repaired block, which is then
+// generically of full rank.  All block operations: no per-column passes over the m x k panel.
+int repair_block(rails_ctx *c, rails_panel *V, int k_old, int w, const std::vector<double> &G, int *n_bad)
+{
+    std::vector<double> R((size_t)w * w, 0.0);
+    std::vector<char> bad(w, 0);
+    *n_bad = 0;
+    for (int i = 0; i < w; ++i) {
+        double piv = G[i + (size_t)i * w];
+        for (int j = 0; j < i; ++j) {
+            if (bad[j]) continue; // row j of R is zero beyond its diagonal
+            double s = G[j + (size_t)i * w];
+            for (int l = 0; l < j; ++l)
+                if (!bad[l]) s -= R[l + (size_t)j * w] * R[l + (size_t)i * w];
+            s /= R[j + (size_t)j * w];
+            R[j + (size_t)i * w] = s;
+            piv -= s * s;
+        }
+        if (piv > 1e-10 * G[i + (size_t)i * w] && G[i + (size_t)i * w] > 0.0)
+            R[i + (size_t)i * w] = std::sqrt(piv);
+        else {
+            bad[i] = 1;
+            R[i + (size_t)i * w] = 1.0;
+            (*n_bad)++;
+        }
+    }
+    std::vector<double> Rinv((size_t)w * w, 0.0);
+    for (int j = 0; j < w; ++j) {
+        Rinv[j + (size_t)j * w] = 1.0 / R[j + (size_t)j * w];
+        for (int i = j - 1; i >= 0; --i) {
+            double s = 0.0;
+            for (int l = i + 1; l <= j; ++l) s += R[i + (size_t)l * w] * Rinv[l + (size_t)j * w];
+            Rinv[i + (size_t)j * w] = -s / R[i + (size_t)i * w];
+        }
+    }
+    double *W = V->d + k_old;
+    RAILS_TRY(rails_small_reserve(c, (size_t)w * w * sizeof(double)));
+    RAILS_TRY(upload_small(c, Rinv, c->small));
+    RAILS_TRY(rails_panel_gemm_dev(c, 1.0, W, V->ld, w, c->small, w, 0.0, W, V->ld, V->m));
+    // norms of the residual columns (one block Gram), then scale them to unit length
+    RAILS_TRY(rails_gram_dev(c, W, V->ld, W, V->ld, V->m, w, w, c->small));
+    RAILS_TRY(rails_allreduce_dev(c, c->small, (size_t)w * w));
+    std::vector<double> G2;
+    RAILS_TRY(sync_small_to_host(c, (size_t)w * w, G2));
+    for (int i = 0; i < w; ++i) {
+        if (!bad[i]) continue;
+        double n2 = G2[i + (size_t)i * w];
+        if (n2 > 0.0 && std::isfinite(n2)) RAILS_TRY(rails_panel_scale(c, V, k_old + i, 1, 1.0 / std::sqrt(n2)));
+    }
+    return RAILS_OK;
+}
+
 } // namespace
 
 extern "C" int rails_orthogonalize(rails_ctx *c, rails_panel *V, int k_old, int w, int method, int *used)
@@ -114,6 +173,8 @@ extern "C" int rails_orthogonalize(rails_ctx *c, rails_panel *V, int k_old, int 
         return columnwise(c, V, k_old, k_old + w);
     }
     double *W = V->d + k_old;
+    for (int round = 0; round < 2; ++round) {
+    bool repaired = false;
     // block CGS2 against the old columns
     if (k_old > 0) {
         RAILS_TRY(rails_small_reserve(c, (size_t)k_old * w * sizeof(double)));
@@ -149,6 +210,19 @@ extern "C" int rails_orthogonalize(rails_ctx *c, rails_panel *V, int k_old, int 
             }
         }
         if (bad) {
+            static const int repair_env = [] {
+                const char *e = getenv("RAILS_ORTH_REPAIR");
+                return e ? atoi(e) : 1;
+            }();
+            if (round == 0 && repair_env && dmax > 0.0) {
+                int n_bad = 0;
+                RAILS_TRY(repair_block(c, V, k_old, w, G, &n_bad));
+                if (n_bad > 0) {
+                    c->n_orth_repair++;
+                    repaired = true;
+                    break; // run the block procedure once more on the repaired block
+                }
+            }
             if (method == 2) {
                 rails_set_error("rails_orthogonalize: block Gram matrix is rank deficient (dpotrf info %d)", info);
                 return RAILS_ELAPACK;
@@ -170,7 +244,12 @@ extern "C" int rails_orthogonalize(rails_ctx *c, rails_panel *V, int k_old, int 
         RAILS_TRY(upload_small(c, Rinv, c->small));
         RAILS_TRY(rails_panel_gemm_dev(c, 1.0, W, V->ld, w, c->small, w, 0.0, W, V->ld, V->m)); // in place, row-local
     }
-    if (used) *used = 2;
-    c->n_orth_block++;
-    return RAILS_OK;
+    if (!repaired) {
+        if (used) *used = round == 0 ? 2 : 3;
+        c->n_orth_block++;
+        return RAILS_OK;
+    }
+    }
+    if (used) *used = 1; // not reached: the second round either succeeds or takes the column-wise path
+    return columnwise_in_block(c, V, k_old, w);
 }

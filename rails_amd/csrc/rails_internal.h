@@ -66,7 +66,7 @@ struct rails_ctx {
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // counters (rails_ctx_stats)
-    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_rowgather = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0;
+    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_rowgather = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0;
 };
 
 struct rails_panel {
