@@ -175,7 +175,7 @@ int rails_orthogonalize(rails_ctx *ctx, rails_panel *V, int k_old, int w, int me
  *   zero-filled then the tridiagonal entries set exactly where the reference sets them.
  *   *steps: Lanczos steps done (< L on breakdown, beta < 1e-14, :419-426).
  * The orthonormal Lanczos vectors q_0..q_{steps-1} stay in a device side buffer of the library until the
- * next call.  Column windows must start at even columns; k <= 512, p <= 128.  Synchronises. */
+ * next call on the same context.  Column windows must start at even columns; k <= 512, p <= 128.  Synchronises. */
 int rails_resid_lanczos(rails_ctx *ctx, const rails_panel *AV, int avc0, const rails_panel *MV, int mvc0, int k,
                         const double *T_host, int ldt, const rails_panel *B, int bc0, int p, int L,
                         double *H_host, int ldh, int *steps);
@@ -191,7 +191,7 @@ int rails_lanczos_start(rails_ctx *ctx, const rails_panel *AV, int avc0, const r
  * host column-major, lds).  Replaces `eigenvectors = Q * v` (src/LyapunovSolver.hpp:443); passing only the
  * selected columns of v writes the expansion vectors straight into V's tail (:338-339). */
 int rails_lanczos_vectors(rails_ctx *ctx, const double *S_host, int lds, int w, rails_panel *Out, int oc0);
-int rails_lanczos_release(void);
+int rails_lanczos_release(rails_ctx *ctx); /* frees the Lanczos vectors kept by the context (also done by rails_ctx_destroy) */
 
 /* ---------------------------------------------------------- timing helpers --- */
 /* HIP-event timing on the context's stream (bench.py's roofline leg). */

@@ -61,7 +61,7 @@ SIGNATURES = {
                                       _dp, C.c_int, _ip]),
     "rails_lanczos_start": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _dp]),
     "rails_lanczos_vectors": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _vp, C.c_int]),
-    "rails_lanczos_release": (C.c_int, []),
+    "rails_lanczos_release": (C.c_int, [_vp]),
     "rails_timer_start": (C.c_int, [_vp]),
     "rails_timer_stop": (C.c_int, [_vp, _dp]),
     "rails_sb03md": (None, [C.c_char, C.c_char, C.c_char, C.c_char, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, _ip]),

@@ -57,6 +57,7 @@ extern "C" int rails_ctx_destroy(rails_ctx *c)
     if (!c) return RAILS_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    rails_lanczos_release(c);
     if (c->ws) hipFree(c->ws);
     if (c->small) hipFree(c->small);
     if (c->pinned) hipHostFree(c->pinned);

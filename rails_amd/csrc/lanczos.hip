@@ -29,7 +29,13 @@ struct rails_lanczos_state {
     size_t small_bytes = 0;
 };
 
-static rails_lanczos_state g_lz; // one solver per thread at most (reference: not thread-safe either)
+// one state per context: the Lanczos vectors of the context's last run (several contexts may live in one process,
+// e.g. one per thread in the single-GPU rank emulation of tests/test_gpu_partition.py)
+static rails_lanczos_state &lz_state(rails_ctx *c)
+{
+    if (!c->lz) c->lz = new rails_lanczos_state();
+    return *static_cast<rails_lanczos_state *>(c->lz);
+}
 
 namespace {
 
@@ -465,7 +471,7 @@ static int lz_run(rails_ctx *c, const rails_panel *AV, int avc0, const rails_pan
     RAILS_REQUIRE(k == 0 || only_start || (T_host && ldt >= k), "rails_resid_lanczos: bad T");
     const int64_t m = AV->m;
     const int64_t mpad = (m + 63) / 64 * 64;
-    rails_lanczos_state &S = g_lz;
+    rails_lanczos_state &S = lz_state(c);
     // Lanczos vectors
     size_t qbytes = (size_t)(L + 2) * (size_t)std::max<int64_t>(mpad, 64) * sizeof(double);
     if (qbytes > S.qc_bytes) {
@@ -598,8 +604,8 @@ extern "C" int rails_lanczos_start(rails_ctx *c, const rails_panel *AV, int avc0
 
 extern "C" int rails_lanczos_vectors(rails_ctx *c, const double *S_host, int lds, int w, rails_panel *Out, int oc0)
 {
-    rails_lanczos_state &S = g_lz;
     RAILS_REQUIRE(c && Out, "rails_lanczos_vectors: null argument");
+    rails_lanczos_state &S = lz_state(c);
     RAILS_REQUIRE(S.Qc && S.steps > 0, "rails_lanczos_vectors: no Lanczos run to take vectors from");
     RAILS_REQUIRE(w >= 0 && oc0 >= 0 && oc0 + w <= Out->cap, "rails_lanczos_vectors: columns [%d,%d) outside capacity %d", oc0, oc0 + w,
                   Out->cap);
@@ -622,11 +628,14 @@ extern "C" int rails_lanczos_vectors(rails_ctx *c, const double *S_host, int lds
     return RAILS_OK;
 }
 
-extern "C" int rails_lanczos_release(void)
+extern "C" int rails_lanczos_release(rails_ctx *c)
 {
-    rails_lanczos_state &S = g_lz;
-    if (S.Qc) hipFree(S.Qc);
-    if (S.small) hipFree(S.small);
-    S = rails_lanczos_state();
+    if (!c || !c->lz) return RAILS_OK;
+    rails_lanczos_state *S = static_cast<rails_lanczos_state *>(c->lz);
+    hipStreamSynchronize(c->stream);
+    if (S->Qc) hipFree(S->Qc);
+    if (S->small) hipFree(S->small);
+    delete S;
+    c->lz = nullptr;
     return RAILS_OK;
 }

@@ -66,6 +66,7 @@ struct rails_ctx {
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // counters (rails_ctx_stats)
+    void *lz = nullptr; // rails_lanczos_state (lanczos.hip), released by rails_lanczos_release
     long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_rowgather = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0;
 };
 

@@ -85,7 +85,7 @@ class Context:
         if self.h:
             for s in list(self._solvers):
                 s.close()
-            self.lib.rails_lanczos_release()
+            self.lib.rails_lanczos_release(self.h)
             self.lib.rails_ctx_destroy(self.h)
             self.h = None
 

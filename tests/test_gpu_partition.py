@@ -1,0 +1,220 @@
+"""The row-partitioned path of the HIP library on ONE GPU: every rank is a thread with its own context,
+stream, CSR row block, ghost-row plan and solver; the all-reduce and halo hooks exchange through host memory between the
+threads (ctypes releases the GIL inside the library, the hooks re-acquire it).  This drives exactly the code an N-GPU
+run drives -- rails_ctx_set_partition, global-row RNG streams, packing + ghost gather in rails_spmm, the hook call sites of
+every reduction, replicated host numerics -- with only torch.distributed/RCCL replaced (that side is covered by the gloo
+world-size 2/3 tests of test_distributed_cpu.py and the world-size-1 RCCL test of test_gpu_hooks.py).
+
+Checked against the oracle on the undivided problem (same seeds: the counter-based generator is keyed on global rows, so
+every partition draws the same start vectors) and against the single-rank GPU run."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class Ranks:
+    """In-process stand-in for the collectives: rank threads meet at a barrier and exchange numpy arrays."""
+
+    def __init__(self, n):
+        self.n = n
+        self.barrier = threading.Barrier(n, timeout=120)
+        self.slots = [None] * n
+        self.plans = [None] * n
+        self.errors = []
+
+    def all_gather_object(self, rank):
+        def fn(obj):
+            self.slots[rank] = obj
+            self.barrier.wait()
+            out = list(self.slots)
+            self.barrier.wait()
+            return out
+        return fn
+
+    def allreduce(self, rank, ctx):
+        import torch
+        from rails_amd.partition import wrap_buffer
+
+        def hook(ptr, n, stream):
+            ctx.sync()  # the library's stream has produced the buffer
+            t = wrap_buffer(ptr, n, True)
+            self.slots[rank] = t.cpu().numpy().copy()
+            self.barrier.wait()
+            total = np.zeros(n)
+            for r in range(self.n):  # fixed order: every rank gets the same bits
+                total += self.slots[r]
+            self.barrier.wait()
+            t.copy_(torch.from_numpy(total))
+            torch.cuda.synchronize()
+            return 0
+        return hook
+
+    def halo(self, rank, ctx, plan):
+        import torch
+        from rails_amd.partition import wrap_buffer
+
+        self.plans[rank] = plan
+
+        def hook(send_ptr, recv_ptr, ncols, stream):
+            ctx.sync()
+            send = wrap_buffer(send_ptr, plan.n_send * ncols, True)
+            self.slots[rank] = send.cpu().numpy().copy()
+            self.barrier.wait()
+            recv = np.zeros(plan.n_ghost * ncols)
+            ro = 0
+            for src in range(self.n):  # my ghosts are grouped by owner, ranks ascending
+                nr = int(plan.recv_counts[src]) * ncols
+                if nr:
+                    ps = self.plans[src]
+                    so = int(ps.send_counts[:rank].sum()) * ncols  # src's send buffer is grouped by destination
+                    assert int(ps.send_counts[rank]) * ncols == nr
+                    recv[ro:ro + nr] = self.slots[src][so:so + nr]
+                ro += nr
+            self.barrier.wait()
+            if plan.n_ghost:
+                wrap_buffer(recv_ptr, plan.n_ghost * ncols, True).copy_(torch.from_numpy(recv))
+            torch.cuda.synchronize()
+            return 0
+        return hook
+
+    def run(self, target):
+        """target(rank) -> result, one thread per rank; re-raises the first failure."""
+        results = [None] * self.n
+
+        def body(r):
+            try:
+                results[r] = target(r)
+            except BaseException as e:  # noqa: BLE001 - reported to the main thread
+                self.errors.append((r, e))
+                self.barrier.abort()
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(self.n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(600)
+        if self.errors:
+            real = [e for e in self.errors if not isinstance(e[1], threading.BrokenBarrierError)] or self.errors
+            raise real[0][1]
+        return results
+
+
+def _rank_setup(ranks, r, starts, A, seed):
+    import rails_amd
+    from rails_amd import partition
+    from rails_amd import problems as P
+
+    m = int(starts[-1])
+    ctx = rails_amd.Context(device=0, seed=seed)
+    ctx.set_partition(r, ranks.n, int(starts[r]), m)
+    rowptr, colg, val = P.csr_rows(A, int(starts[r]), int(starts[r + 1]))
+    plan = partition.HaloPlan(starts, r, colg, ranks.all_gather_object(r))
+    op = rails_amd.HipOperatorWrapper(ctx, rowptr, plan.col_local, val, ncols_ext=plan.m_local + plan.n_ghost)
+    op.set_halo(plan, ranks.halo(r, ctx, plan))
+    ctx.set_allreduce(ranks.allreduce(r, ctx))
+    return ctx, op, plan
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_partitioned_spmm_and_reductions(oracle, nranks):
+    from rails_amd import partition
+    from rails_amd import problems as P
+    from rails_amd.wrappers import HipMultiVectorWrapper as MV
+
+    A = P.banded_random(5000, 27, 300, seed=1)
+    m = 5000
+    g = np.random.default_rng(3)
+    X = g.uniform(-1, 1, (m, 24))
+    starts = partition.row_ranges(m, nranks)
+    ranks = Ranks(nranks)
+
+    def work(r):
+        ctx, op, plan = _rank_setup(ranks, r, starts, A, seed=5)
+        r0, r1 = int(starts[r]), int(starts[r + 1])
+        out = {}
+        for nc in (24, 16, 3):
+            Y = op.apply(MV(ctx, data=X[r0:r1, :nc]))
+            out["Y%d" % nc] = Y.to_host()
+        Xl = MV(ctx, data=X[r0:r1])
+        out["gram"] = Xl.view(0, 7).dot(Xl.view(8, 23))  # all-reduced over the ranks
+        Rn = MV(ctx, m=r1 - r0, n=3, capacity=4)
+        Rn.random()  # stream 0, global rows r0..r1
+        out["rand"] = Rn.to_host()
+        out["ghosts"] = plan.n_ghost
+        ctx.close()
+        return out
+
+    res = ranks.run(work)
+    for nc in (24, 16, 3):
+        Y = np.vstack([res[r]["Y%d" % nc] for r in range(nranks)])
+        ref = oracle.csr_spmm(*A, X[:, :nc])
+        assert np.abs(Y - ref).max() <= 1e-13 * np.abs(ref).max()
+    G = X[:, :8].T @ X[:, 8:]
+    for r in range(nranks):
+        assert res[r]["ghosts"] > 0
+        np.testing.assert_allclose(res[r]["gram"], G, atol=1e-11)
+        assert np.array_equal(res[r]["gram"], res[0]["gram"])  # replicated small objects are bit-identical on every rank
+    assert np.array_equal(np.vstack([res[r]["rand"] for r in range(nranks)]), oracle.random(m, 3, mode=1, seed=5, stream=0))
+
+
+@pytest.mark.parametrize("nranks,projected", [(2, 0), (3, 0), (2, 1)])
+def test_partitioned_solve_matches_oracle_and_single_rank(oracle, nranks, projected):
+    import rails_amd
+    from rails_amd import partition
+    from rails_amd import problems as P
+
+    A = P.laplace7(20, 20, 15)
+    m = A[0].size - 1
+    B = P.rhs(m, 8, seed=5)
+    params = {"Restart size": 64, "Reduced size": 32, "Expand size": 8, "Lanczos iterations": 10, "Tolerance": 1e-3}
+    seed = 3
+    starts = partition.row_ranges(m, nranks)
+    ranks = Ranks(nranks)
+
+    def work(r):
+        ctx, op, plan = _rank_setup(ranks, r, starts, A, seed=seed)
+        r0, r1 = int(starts[r]), int(starts[r + 1])
+        s = rails_amd.Solver(ctx, op, B[r0:r1], m_global=m)
+        assert s.set_parameters(params) == 0
+        s.set_option("verbose", 0)
+        s.set_option("projected_lanczos", projected)
+        code, V, T = s.solve()
+        out = dict(code=code, V=V, T=T, hist=s.history(), trips=s.trips(), rel=s.relative_residual(), stats=ctx.stats())
+        s.close()
+        ctx.close()
+        return out
+
+    res = ranks.run(work)
+    out = oracle.solve(A, B, oracle.params({**params, "rng_mode": 1, "seed": seed}))
+    V = np.vstack([res[r]["V"] for r in range(nranks)])
+    T = res[0]["T"]
+    for r in range(nranks):
+        assert res[r]["code"] == 0 == out["ret"]
+        assert res[r]["trips"] == res[0]["trips"]
+        assert np.array_equal(res[r]["T"], T)  # replicated
+        assert np.array_equal(res[r]["hist"], res[0]["hist"])
+        assert res[r]["stats"]["allreduce"] > 0
+        if projected:
+            assert res[r]["stats"]["lanczos_start"] > 0
+    assert abs(res[0]["trips"] - out["trips"]) <= 1
+    h, ho = res[0]["hist"], out["res_hist"]
+    n = min(6, len(h), len(ho))
+    np.testing.assert_allclose(h[:n], ho[:n], rtol=1e-6)
+    Xg, Xo = V @ T @ V.T, out["V"] @ out["T"] @ out["V"].T
+    assert np.linalg.norm(Xg - Xo) / np.linalg.norm(Xo) <= 1e-2
+    assert np.abs(V.T @ V - np.eye(V.shape[1])).max() < 1e-10
+    assert res[0]["rel"] < 5e-3
+    # single-rank GPU run of the same problem
+    ctx = rails_amd.Context(device=0, seed=seed)
+    s = rails_amd.Solver(ctx, rails_amd.HipOperatorWrapper(ctx, *A), B)
+    assert s.set_parameters(params) == 0
+    s.set_option("verbose", 0)
+    s.set_option("projected_lanczos", projected)
+    code, V1, T1 = s.solve()
+    assert code == 0 and abs(s.trips() - res[0]["trips"]) <= 1
+    X1 = V1 @ T1 @ V1.T
+    assert np.linalg.norm(Xg - X1) / np.linalg.norm(X1) <= 1e-2
+    s.close()
+    ctx.close()
