@@ -1,0 +1,601 @@
+// Contract test of the three classes that plug into Solver<Matrix, MultiVector, DenseMatrix> (the drop-in boundary,
+// SURVEY.md 8(b)): rails::HipOperatorWrapper, rails::HipMultiVectorWrapper, rails::HostDenseMatrix.  The cases restate, for these
+// classes, what the reference's typed tests demand of every back end:
+//   test/GenericMultiVectorWrapper_test.cpp:63-507, test/GenericOperatorWrapper_test.cpp:74-114,187-229,
+//   test/GenericDenseMatrixWrapper_test.cpp:61-209
+// (the reference gets element access from a `Testable...` subclass, test/Epetra_TestableWrappers.hpp:14-95; here element
+// access goes through host round trips of single columns).  Operator eigs() (GenericOperatorWrapper_test.cpp:116-185) is an
+// optional member the solver never calls and is not provided.
+//
+//   wrapper_contract            all cases (needs a gfx950 GPU)
+//   wrapper_contract --host     DenseMatrix cases only (no GPU needed)
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "rails/HipSolverOps.hpp"
+
+using rails::HipMultiVectorWrapper;
+using rails::HipOperatorWrapper;
+using rails::HostDenseMatrix;
+
+static int g_fail = 0, g_checks = 0;
+static const char *g_case = "";
+
+#define CHECK(cond)                                                                          \
+    do {                                                                                     \
+        ++g_checks;                                                                          \
+        if (!(cond)) {                                                                       \
+            ++g_fail;                                                                        \
+            std::printf("FAIL [%s] %s:%d: %s\n", g_case, __FILE__, __LINE__, #cond);          \
+        }                                                                                    \
+    } while (0)
+#define CHECK_NEAR(a, b, tol)                                                                                  \
+    do {                                                                                                       \
+        ++g_checks;                                                                                            \
+        double xa_ = (a), xb_ = (b);                                                                           \
+        if (!(std::abs(xa_ - xb_) <= (tol))) {                                                                 \
+            ++g_fail;                                                                                          \
+            std::printf("FAIL [%s] %s:%d: %s = %.17g vs %s = %.17g\n", g_case, __FILE__, __LINE__, #a, xa_, #b, xb_); \
+        }                                                                                                      \
+    } while (0)
+
+// ---- element access for the device multivector --------------------------------------------------------------------------
+static std::vector<double> host_of(HipMultiVectorWrapper const &v) // column-major M x N
+{
+    int m = (int)v.local_rows(), n = v.N();
+    std::vector<double> h((size_t)m * std::max(n, 0));
+    if (n > 0) v.to_host(h.data(), m);
+    return h;
+}
+static double get(HipMultiVectorWrapper const &v, int i, int j) { return host_of(v)[i + (size_t)j * v.local_rows()]; }
+static void set(HipMultiVectorWrapper &v, int i, int j, double x)
+{
+    int m = (int)v.local_rows();
+    std::vector<double> col(m);
+    HipMultiVectorWrapper c = v.view(j);
+    c.to_host(col.data(), m);
+    col[i] = x;
+    int w = v.orthogonalized();
+    c.from_host(col.data(), m);
+    v.set_orthogonalized(std::min(w, j)); // writing into column j invalidates the watermark from there on
+}
+static bool same(HipMultiVectorWrapper const &a, HipMultiVectorWrapper const &b, double tol = 0.0)
+{
+    if (a.M() != b.M() || a.N() != b.N()) return false;
+    std::vector<double> ha = host_of(a), hb = host_of(b);
+    for (size_t i = 0; i < ha.size(); ++i)
+        if (!(std::abs(ha[i] - hb[i]) <= tol)) return false;
+    return true;
+}
+static bool orthonormal(HipMultiVectorWrapper const &a)
+{
+    HostDenseMatrix G = a.dot(a);
+    for (int i = 0; i < G.M(); ++i)
+        for (int j = 0; j < G.N(); ++j)
+            if (std::abs(G(i, j) - (i == j ? 1.0 : 0.0)) > 1e-14) return false;
+    return true;
+}
+
+struct MVFixture { // four 10 x 10 multivectors, one column in use (GenericMultiVectorWrapper_test.cpp:14-48)
+    HipMultiVectorWrapper a, b, c, d;
+    explicit MVFixture(rails_ctx *ctx) : a(10, 10, ctx), b(10, 10, ctx), c(10, 10, ctx), d(10, 10, ctx) { resize(1); }
+    void resize(int n)
+    {
+        a.resize(n);
+        b.resize(n);
+        c.resize(n);
+        d.resize(n);
+    }
+};
+
+static void multivector_cases(rails_ctx *ctx)
+{
+    auto run = [&](const char *name, std::function<void(MVFixture &)> body) {
+        g_case = name;
+        MVFixture f(ctx);
+        body(f);
+    };
+    run("MV.Resize", [](MVFixture &f) {
+        f.a.resize(0);
+        CHECK(f.a.N() == 0);
+        f.a.resize(0);
+        CHECK(f.a.N() == 0);
+        f.a.resize(2);
+        CHECK(f.a.N() == 2);
+        f.a.resize(1);
+        CHECK(f.a.N() == 1);
+    });
+    run("MV.PutScalar", [](MVFixture &f) {
+        f.a = 2.0;
+        for (int i = 0; i < 10; ++i) CHECK(get(f.a, i, 0) == 2.0);
+    });
+    run("MV.Assignment shares storage", [](MVFixture &f) {
+        f.a.random();
+        f.b = f.a;
+        f.b = 2.0;
+        CHECK(same(f.b, f.a));
+        CHECK(get(f.a, 3, 0) == 2.0);
+    });
+    run("MV.ScaleAssign", [](MVFixture &f) {
+        f.a.random();
+        f.b = f.a.copy();
+        f.b *= 2.5;
+        for (int i = 0; i < 10; ++i) CHECK(get(f.b, i, 0) == get(f.a, i, 0) * 2.5);
+    });
+    run("MV.AddAssign", [](MVFixture &f) {
+        f.a.random();
+        f.b = f.a.copy();
+        f.b += f.a;
+        f.a *= 2.0;
+        CHECK(same(f.a, f.b));
+    });
+    run("MV.SubAssign", [](MVFixture &f) {
+        f.a.random();
+        f.b = f.a.copy();
+        f.b -= f.a;
+        f.a = 0.0;
+        CHECK(same(f.a, f.b));
+    });
+    run("MV.DivAssign", [](MVFixture &f) {
+        f.a.random();
+        f.b = f.a.copy();
+        f.b *= 1.0 / 13.0;
+        f.a /= 13;
+        CHECK(same(f.a, f.b));
+    });
+    run("MV.Addition", [](MVFixture &f) {
+        f.a.random();
+        f.b = f.a.copy();
+        f.b *= 2.0;
+        f.d = f.a + f.b;
+        for (int i = 0; i < 10; ++i) CHECK(get(f.d, i, 0) == get(f.a, i, 0) + get(f.b, i, 0));
+        CHECK(!same(f.d, f.a)); // a + b is a new object
+    });
+    run("MV.ScalarTimes", [](MVFixture &f) {
+        f.a.random();
+        f.b = f.a.copy();
+        f.b *= 13.0;
+        f.c = 13 * f.a;
+        CHECK(same(f.b, f.c));
+    });
+    run("MV.Norm", [](MVFixture &f) {
+        f.a.random();
+        double s = 0.0;
+        for (int i = 0; i < 10; ++i) s += get(f.a, i, 0) * get(f.a, i, 0);
+        CHECK_NEAR(std::sqrt(s), f.a.norm(), 4e-16 * std::sqrt(s));
+        f.a /= f.a.norm();
+        CHECK_NEAR(1.0, f.a.norm(), 4e-16);
+    });
+    run("MV.NormView", [](MVFixture &f) {
+        f.resize(2);
+        f.a.random();
+        double n1 = 0.0, n2 = 0.0;
+        for (int i = 0; i < 10; ++i) {
+            n1 += get(f.a, i, 0) * get(f.a, i, 0);
+            n2 += get(f.a, i, 1) * get(f.a, i, 1);
+        }
+        n1 = std::sqrt(n1);
+        n2 = std::sqrt(n2);
+        CHECK(n1 != 0.0 && n2 != 0.0 && n1 != n2);
+        CHECK_NEAR(n1, f.a.view(0).norm(), 4e-16 * n1);
+        CHECK_NEAR(n2, f.a.view(1).norm(), 4e-16 * n2);
+        CHECK(f.a.N() == 2);
+        CHECK(f.a.norm() != n1 && f.a.norm() != n2); // 2-norm of the pair, not of a column
+    });
+    run("MV.Dot", [](MVFixture &f) {
+        f.a.random();
+        f.b.random();
+        double s = 0.0;
+        for (int i = 0; i < 10; ++i) s += get(f.a, i, 0) * get(f.b, i, 0);
+        HostDenseMatrix c = f.a.dot(f.b);
+        CHECK(c.M() == 1 && c.N() == 1);
+        CHECK_NEAR(s, c(0, 0), 1e-15);
+    });
+    run("MV.Dot unequal widths", [](MVFixture &f) {
+        f.a.resize(2);
+        f.a.random();
+        f.b.resize(3);
+        f.b.random();
+        HostDenseMatrix c = f.a.dot(f.b);
+        CHECK(c.M() == 2 && c.N() == 3);
+        for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < 2; ++j) {
+                double s = 0.0;
+                for (int i = 0; i < 10; ++i) s += get(f.a, i, j) * get(f.b, i, k);
+                CHECK_NEAR(s, c(j, k), 1e-15);
+            }
+    });
+    run("MV.Orthogonalize known answer", [](MVFixture &f) {
+        f.resize(2);
+        f.a = 0.0;
+        set(f.a, 0, 0, 2.3);
+        set(f.a, 0, 1, 5.3);
+        set(f.a, 1, 1, 2.7);
+        f.a.orthogonalize();
+        f.b = 0.0;
+        set(f.b, 0, 0, 1.0);
+        set(f.b, 1, 1, 1.0);
+        CHECK(same(f.b, f.a, 4e-16));
+    });
+    run("MV.Orthogonalize push_back watermark", [](MVFixture &f) {
+        f.a = 0.0;
+        set(f.a, 0, 0, 2.3);
+        f.b = 0.0;
+        set(f.b, 0, 0, 1.0);
+        f.a.orthogonalize();
+        CHECK(same(f.b, f.a, 4e-16));
+        f.b.resize(2);
+        f.b = 0.0;
+        set(f.b, 0, 0, 1.0);
+        set(f.b, 1, 1, 1.0);
+        f.c = 0.0;
+        set(f.c, 0, 0, 5.3);
+        set(f.c, 1, 0, 2.7);
+        f.a.push_back(f.c);
+        f.a.orthogonalize();
+        CHECK(same(f.b, f.a, 4e-16));
+    });
+    run("MV.Orthogonalize random", [](MVFixture &f) {
+        f.a.resize(3);
+        f.a.random();
+        f.a.orthogonalize();
+        CHECK(orthonormal(f.a));
+        f.b.resize(3);
+        f.b.random();
+        f.a.push_back(f.b);
+        f.a.orthogonalize();
+        CHECK(orthonormal(f.a));
+        CHECK(f.a.N() == 6);
+    });
+    run("MV.Orthogonalize after modification", [](MVFixture &f) {
+        f.a.resize(3);
+        f.a.random();
+        f.a.orthogonalize();
+        CHECK(orthonormal(f.a));
+        f.a.random();
+        f.a.orthogonalize();
+        CHECK(orthonormal(f.a));
+        f.a *= 2.0;
+        f.a.orthogonalize();
+        CHECK(orthonormal(f.a));
+        f.a *= 3.3;
+        f.a.orthogonalize();
+        CHECK(orthonormal(f.a));
+        f.a /= 2.6;
+        f.a.orthogonalize();
+        CHECK(orthonormal(f.a));
+        f.a.view(2).random();
+        f.a.resize(2);
+        f.a.resize(3);
+        f.a.orthogonalize();
+        CHECK(orthonormal(f.a));
+    });
+    run("MV.Resize after sharing", [](MVFixture &f) {
+        f.a.resize(20);
+        CHECK(f.a.N() == 20);
+        f.a.random();
+        f.a.resize(0);
+        CHECK(f.a.N() == 0);
+        f.b.resize(10);
+        f.b.random();
+        f.a = f.b;
+        CHECK(f.a.N() == 10);
+        CHECK(same(f.b, f.a));
+        f.a.resize(10);
+        CHECK(f.a.N() == 10);
+        CHECK(same(f.b, f.a));
+    });
+    run("MV.Resize keeps data inside the capacity", [](MVFixture &f) {
+        f.a.resize(1);
+        f.a.random();
+        f.b = f.a.copy();
+        f.a.resize(10);
+        f.c = f.a.view(0);
+        CHECK(same(f.b, f.c));
+    });
+    run("MV.View assigns through", [](MVFixture &f) {
+        f.a.random();
+        f.b = f.a.copy();
+        f.b.random();
+        f.a.view(0) = f.b;
+        CHECK(same(f.b, f.a));
+    });
+    run("MV.View of a shared object", [](MVFixture &f) {
+        f.a.random();
+        f.b = f.a;
+        CHECK(same(f.b, f.a));
+        f.c.random();
+        f.b = f.c;
+        CHECK(same(f.b, f.c));
+        CHECK(get(f.a, 0, 0) != get(f.b, 0, 0));
+        f.b = f.a;
+        f.b.view() = f.c;
+        CHECK(same(f.a, f.c));
+        CHECK(same(f.b, f.c));
+    });
+    run("MV.Copy is deep", [](MVFixture &f) {
+        f.a.random();
+        f.b = f.a;
+        f.b.random();
+        CHECK(same(f.b, f.a));
+        f.b = f.a.copy();
+        CHECK(same(f.b, f.a));
+        f.b.random();
+        CHECK(get(f.a, 0, 0) != get(f.b, 0, 0));
+        HipMultiVectorWrapper other = f.a.copy();
+        CHECK(same(f.a, other));
+        other.random();
+        CHECK(get(f.a, 0, 0) != get(other, 0, 0));
+    });
+    run("MV.PushBack", [](MVFixture &f) {
+        f.a.resize(3);
+        f.a.random();
+        f.b = f.a.view(0).copy();
+        f.b.push_back(f.a.view(1));
+        f.b.push_back(f.a.view(2));
+        CHECK(same(f.b, f.a));
+        f.a.random();
+        f.b = f.a.view(0).copy();
+        f.b.push_back(f.a.view(1, 2));
+        CHECK(same(f.b, f.a));
+    });
+    run("MV.Transpose products", [ctx](MVFixture &f) {
+        // (10 x 10)' * (10 x 1) is the B'W shape of the solver: a small replicated result; (10 x 10) * y is the B*y shape
+        // with y a replicated 10 x 1 object (src/MatrixOrMultiVectorWrapper.hpp:54,59)
+        f.a.resize(10);
+        f.a = 0.0;
+        set(f.a, 0, 0, 1);
+        set(f.a, 0, 1, 2);
+        set(f.a, 1, 0, 3);
+        set(f.a, 1, 1, 4);
+        f.b.resize(1);
+        f.b.random();
+        double b0 = get(f.b, 0, 0), b1 = get(f.b, 1, 0);
+        HipMultiVectorWrapper c = f.a.transpose() * f.b;
+        CHECK(c.replicated() && c.M() == 10 && c.N() == 1);
+        CHECK_NEAR(b0 + 3.0 * b1, c.host_data()[0], 1e-14);
+        CHECK_NEAR(2.0 * b0 + 4.0 * b1, c.host_data()[1], 1e-14);
+        HipMultiVectorWrapper y = HipMultiVectorWrapper::Replicated(10, 1, ctx);
+        std::vector<double> hb = host_of(f.b);
+        y.from_host(hb.data(), 10);
+        HipMultiVectorWrapper d = f.a * y;
+        CHECK(!d.replicated() && d.M() == 10 && d.N() == 1);
+        CHECK_NEAR(b0 + 2.0 * b1, get(d, 0, 0), 1e-14);
+        CHECK_NEAR(3.0 * b0 + 4.0 * b1, get(d, 1, 0), 1e-14);
+    });
+    run("MV.Transpose shapes", [](MVFixture &f) {
+        f.a.resize(1);
+        CHECK(f.a.M() == 10 && f.a.N() == 1);
+        CHECK(f.a.transpose().M() == 1 && f.a.transpose().N() == 10);
+    });
+    run("MV.Construct like another", [](MVFixture &f) { // (other, n): same rows, n columns (src/StlWrapper.cpp:46-51; uses :125,156,372)
+        f.a.resize(3);
+        HipMultiVectorWrapper q(f.a, 7);
+        CHECK(q.M() == 10 && q.N() == 7 && q.capacity() >= 7);
+        HipMultiVectorWrapper e;
+        e.push_back(f.a.view(1)); // default-constructed target (src/LyapunovSolver.hpp:129)
+        CHECK(e.N() == 1 && same(e, f.a.view(1)));
+    });
+}
+
+// 10 x 10 operator from a dense array (explicit zeros dropped)
+static HipOperatorWrapper op_from_dense(rails_ctx *ctx, std::vector<double> const &E, int n)
+{
+    std::vector<int64_t> rp(n + 1, 0);
+    std::vector<int32_t> ci;
+    std::vector<double> va;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j)
+            if (E[i + (size_t)j * n] != 0.0) {
+                ci.push_back(j);
+                va.push_back(E[i + (size_t)j * n]);
+            }
+        rp[i + 1] = (int64_t)ci.size();
+    }
+    if (ci.empty()) {
+        ci.push_back(0);
+        va.push_back(0.0);
+    }
+    return HipOperatorWrapper(ctx, n, n, rp.data(), ci.data(), va.data());
+}
+
+static void operator_cases(rails_ctx *ctx)
+{
+    const int n = 10;
+    std::vector<double> E((size_t)n * n, 0.0);
+    E[0 + 0 * n] = 1;
+    E[0 + 1 * n] = 2;
+    E[1 + 0 * n] = 3;
+    E[1 + 1 * n] = 4;
+    HipOperatorWrapper A = op_from_dense(ctx, E, n);
+    HipMultiVectorWrapper a(n, 1, ctx);
+    g_case = "Op.Apply";
+    a.random();
+    double a0 = get(a, 0, 0), a1 = get(a, 1, 0);
+    HipMultiVectorWrapper b = A * a;
+    CHECK_NEAR(a0 + 2.0 * a1, get(b, 0, 0), 1e-14);
+    CHECK_NEAR(3.0 * a0 + 4.0 * a1, get(b, 1, 0), 1e-14);
+    CHECK_NEAR(0.0, get(b, 5, 0), 0.0);
+    g_case = "Op.Transpose";
+    HipMultiVectorWrapper bt = A.transpose() * a;
+    HipMultiVectorWrapper c = A * a;
+    CHECK_NEAR(a0 + 3.0 * a1, get(bt, 0, 0), 1e-14);
+    CHECK_NEAR(2.0 * a0 + 4.0 * a1, get(bt, 1, 0), 1e-14);
+    CHECK_NEAR(a0 + 2.0 * a1, get(c, 0, 0), 1e-14);
+    CHECK_NEAR(3.0 * a0 + 4.0 * a1, get(c, 1, 0), 1e-14);
+    CHECK(A.M() == n && A.N() == n && A.transpose().M() == n);
+    HipOperatorWrapper copyA(A); // cheap handle copies share the device matrix (src/LyapunovSolverDecl.hpp:37-39)
+    CHECK(copyA.csr() == A.csr());
+    HipOperatorWrapper empty;
+    CHECK(empty.csr() == nullptr);
+    g_case = "Op.Norm rank one";
+    HipMultiVectorWrapper V(n, n, ctx);
+    V.view(0).random();
+    std::vector<double> hv = host_of(V.view(0));
+    std::fill(E.begin(), E.end(), 0.0);
+    for (int i = 0; i < n; ++i) E[i] = hv[i];
+    HipOperatorWrapper E1 = op_from_dense(ctx, E, n);
+    CHECK(E1.norm() != 0.0);
+    CHECK_NEAR(V.view(0).norm(), E1.norm(), 1e-13 * V.view(0).norm());
+    g_case = "Op.Norm symmetric";
+    V.random();
+    std::vector<double> H = host_of(V);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) H[i + (size_t)j * n] = H[j + (size_t)i * n];
+    V.from_host(H.data(), n);
+    HipOperatorWrapper E2 = op_from_dense(ctx, H, n);
+    HostDenseMatrix DV, D;
+    V.dot(V).eigs(DV, D);
+    double mx = 0.0;
+    for (int i = 0; i < n; ++i) mx = std::max(mx, std::sqrt(std::abs(D(i, 0))));
+    CHECK(mx != 0.0);
+    CHECK_NEAR(mx, E2.norm(), 1e-7 * mx); // power iteration on A'A: converged to the iteration's own stopping rule, not to the last bit
+}
+
+static void dense_cases()
+{
+    const double r45 = std::sqrt(45.0);
+    {
+        g_case = "Dense.Eigs 2x2";
+        HostDenseMatrix A(2, 2), B(2, 2), C(2, 1);
+        A(0, 0) = 1;
+        A(0, 1) = 3;
+        A(1, 0) = 3;
+        A(1, 1) = 4;
+        A.eigs(B, C);
+        CHECK_NEAR((5.0 - r45) / 2.0, C(0, 0), 1e-12);
+        CHECK_NEAR((5.0 + r45) / 2.0, C(1, 0), 1e-12);
+        // eigenvectors: A v = lambda v
+        for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < 2; ++i) CHECK_NEAR(A(i, 0) * B(0, k) + A(i, 1) * B(1, k), C(k, 0) * B(i, k), 1e-12);
+    }
+    {
+        g_case = "Dense.Eigs after shrinking";
+        HostDenseMatrix D(10, 10), B, C(4, 1);
+        D = 0.0;
+        D(0, 5) = 10.0;
+        D(5, 0) = 10.0;
+        D.resize(4, 4); // the entries outside the 4 x 4 window must not leak into the eigenproblem
+        D(0, 0) = 1;
+        D(0, 1) = 3;
+        D(1, 0) = 3;
+        D(1, 1) = 4;
+        D.eigs(B, C);
+        std::vector<int> idx;
+        rails::find_largest_eigenvalues(C, idx, 4);
+        CHECK_NEAR((5.0 + r45) / 2.0, C(idx[0], 0), 1e-12);
+        CHECK_NEAR((5.0 - r45) / 2.0, C(idx[1], 0), 1e-12);
+    }
+    {
+        g_case = "Dense.PutScalar/Scale";
+        HostDenseMatrix A(2, 2), D(10, 10);
+        A = 2.0;
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) CHECK(A(i, j) == 2.0);
+        A *= 1.5;
+        CHECK(A(1, 1) == 3.0);
+        D = 0.0;
+        D(1, 1) = 1.0;
+        D.resize(2, 2);
+        D = 0.0;
+        CHECK(D(1, 1) == 0.0 && D.M() == 2 && D.N() == 2);
+    }
+    {
+        g_case = "Dense.Resize";
+        HostDenseMatrix A(2, 2);
+        A = 0.0;
+        A(0, 0) = 10.0;
+        A.resize(80, 100);
+        CHECK(A.M() == 80 && A.LDA() == 80 && A.N() == 100);
+        CHECK(A(0, 0) == 10.0);
+        HostDenseMatrix E;
+        E.resize(10, 10);
+        CHECK(E.M() == 10 && E.N() == 10);
+        // shrinking and growing inside the capacity keeps contents AND leading dimension (src/LyapunovSolver.hpp:165,323)
+        HostDenseMatrix G(6, 6);
+        for (int j = 0; j < 6; ++j)
+            for (int i = 0; i < 6; ++i) G(i, j) = i + 10.0 * j;
+        G.resize(3, 3);
+        CHECK(G.LDA() == 6 && G(2, 2) == 22.0);
+        G.resize(5, 5);
+        CHECK(G.LDA() == 6 && G(4, 3) == 34.0);
+        double *raw = G;
+        CHECK(raw[4 + 3 * 6] == 34.0); // operator double* + LDA is what sb03md receives (:357)
+    }
+    {
+        g_case = "Dense.View";
+        HostDenseMatrix A(2, 2), D(10, 10);
+        A = 2.0;
+        D = 1.0;
+        D.resize(2, 2);
+        D.view() = A;
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) CHECK(D(i, j) == 2.0);
+        D.resize(10, 10);
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) CHECK(D(i, j) == 2.0);
+        CHECK(D(5, 5) == 1.0);
+        HostDenseMatrix S;
+        S = A; // assignment to a non-view shares
+        S(0, 0) = 7.0;
+        CHECK(A(0, 0) == 7.0);
+        HostDenseMatrix Cp = A.copy();
+        Cp(0, 0) = 8.0;
+        CHECK(A(0, 0) == 7.0);
+    }
+    {
+        g_case = "Dense.NormInf";
+        HostDenseMatrix A(2, 2);
+        A(0, 0) = 1;
+        A(0, 1) = 3;
+        A(1, 0) = -3;
+        A(1, 1) = 4;
+        CHECK(A.norm_inf() == 7.0);
+    }
+    {
+        g_case = "Dense.Transpose";
+        HostDenseMatrix A(2, 2), a(2, 1);
+        A(0, 0) = 1;
+        A(0, 1) = 2;
+        A(1, 0) = 3;
+        A(1, 1) = 4;
+        a(0, 0) = 1.2423;
+        a(1, 0) = -4.9693;
+        HostDenseMatrix b = A.transpose() * a, c = A * a;
+        CHECK_NEAR(a(0, 0) + 3.0 * a(1, 0), b(0, 0), 1e-14);
+        CHECK_NEAR(2.0 * a(0, 0) + 4.0 * a(1, 0), b(1, 0), 1e-14);
+        CHECK_NEAR(a(0, 0) + 2.0 * a(1, 0), c(0, 0), 1e-14);
+        CHECK_NEAR(3.0 * a(0, 0) + 4.0 * a(1, 0), c(1, 0), 1e-14);
+        CHECK(a.M() == 2 && a.N() == 1 && a.transpose().M() == 1 && a.transpose().N() == 2);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    bool host_only = argc > 1 && std::strcmp(argv[1], "--host") == 0;
+    if (rails_host_lapack_init(nullptr) != RAILS_OK) {
+        std::printf("no host LAPACK: %s\n", rails_last_error());
+        return 2;
+    }
+    dense_cases();
+    if (!host_only) {
+        rails_ctx *ctx = nullptr;
+        if (rails_ctx_create(0, nullptr, &ctx) != RAILS_OK) {
+            std::printf("rails_ctx_create failed: %s\n", rails_last_error());
+            return 2;
+        }
+        rails_ctx_set_seed(ctx, 11, 0);
+        rails::set_default_context(ctx);
+        multivector_cases(ctx);
+        operator_cases(ctx);
+        rails_ctx_destroy(ctx);
+    }
+    std::printf("%s: %d checks, %d failures\n", host_only ? "host cases" : "all cases", g_checks, g_fail);
+    if (g_fail == 0) std::printf("ALL PASSED\n");
+    return g_fail == 0 ? 0 : 1;
+}
