@@ -116,7 +116,7 @@ int rails_spmm(rails_ctx *ctx, rails_csr *A, int trans, const rails_panel *X, in
 
 /* Kernel variant control for benchmarking and tests: 0 = auto, 1 = row-gather kernel (column chunking by the window
  * heuristic), 2 = LDS-staged footprint kernel, 3 = row-gather over the whole width, 4 / 5 = row-gather in 32 / 64 column
- * chunks inside one launch. */
+ * chunks inside one launch, 6 = LDS-staged footprint kernel with 16-column chunks (whole 128-B lines per staged row). */
 int rails_csr_set_variant(rails_csr *A, int variant);
 /* name of the kernel the last rails_spmm on A launched */
 const char *rails_csr_last_kernel(const rails_csr *A);

@@ -381,7 +381,7 @@ extern "C" const char *rails_csr_last_kernel(const rails_csr *A) { return A ? A-
 
 extern "C" int rails_csr_set_variant(rails_csr *A, int variant)
 {
-    RAILS_REQUIRE(A && variant >= 0 && variant <= 5, "rails_csr_set_variant: bad argument");
+    RAILS_REQUIRE(A && variant >= 0 && variant <= 6, "rails_csr_set_variant: bad argument");
     A->variant = variant;
     return RAILS_OK;
 }
@@ -469,10 +469,10 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     }
     bool done = false;
     const bool vec2 = ((xc0 | yc0) & 1) == 0 && (ldg % 2 == 0);
-    if (A->variant == 0 || A->variant == 2) RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, vec2, X->ld - xc0, &done));
+    if (A->variant == 0 || A->variant == 2 || A->variant == 6) RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, vec2, X->ld - xc0, &done));
     if (done) c->n_spmm_tiled++;
     if (!done) {
-        RAILS_REQUIRE(A->variant != 2, "rails_spmm: LDS-staged kernel requested but not applicable to this operator/shape");
+        RAILS_REQUIRE(A->variant != 2 && A->variant != 6, "rails_spmm: LDS-staged kernel requested but not applicable to this operator/shape");
         const int cc = vec2 ? rowgather_chunk(A, nc) : 0;
         if (cc == 32)
             RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
@@ -722,7 +722,14 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_pipe(int64_t m, int64_t ntil
 // into registers once per tile and reused for every column chunk, so the inner loop is ONE ds_read_b128 + 2 FMA per
 // nonzero (the LDS-resident forms above spend three LDS reads per nonzero and are LDS-issue bound).  X chunks are
 // double-buffered in LDS, the next chunk's global loads are in flight during the current chunk's arithmetic.
-template <int KC, int NNZ, int NL>
+//
+// V2 = double2 vectors per lane: V2 = 1 gives KC/2 lanes per row (KC = 8: 4 lanes x 16 B); V2 = 2 with KC = 16 keeps 4 lanes
+// per row (64-row tiles) with 32 B per lane, i.e. whole 128-B lines per staged X row, twice the bytes in flight per
+// workgroup at the same register cost for the row's CSR, and half as many barrier phases.  The two 64-B halves of an LDS
+// row are swapped when bit 1 of the row position is set, so the four x-consecutive row slots a 16-lane group of a
+// ds_read_b128 serves still fall into four different bank quarters.
+// NS = column chunks in flight in registers per thread (2, or 1 where the registers do not allow two).
+template <int KC, int NNZ, int NL, int V2, int NS>
 __global__ __launch_bounds__(256) void k_spmm_tiled_reg(int64_t m, int64_t ntiles, const int32_t *__restrict__ t_rowptr,
                                                         const int32_t *__restrict__ t_rows, const int64_t *__restrict__ t_nzptr,
                                                         const int32_t *__restrict__ t_rp, const double *__restrict__ t_val,
@@ -735,7 +742,9 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_reg(int64_t m, int64_t ntile
     // guaranteed by the host): a load under a lane-dependent branch makes hipcc wait vmcnt(0) at the join, which
     // serialises the staging loads into dependent round trips (measured: 4 us per 14-KB chunk).
     extern __shared__ double smem[];
-    constexpr int LPR = KC / 2;
+    constexpr int LPR = KC / (2 * V2); // compute lanes per row
+    constexpr int SPR = KC / 2;        // 16-byte staging pieces per row
+    static_assert(V2 == 1 || (V2 == 2 && KC == 16), "supported: one double2 per lane, or two with 16-column chunks");
     int64_t t = blockIdx.x;
     if (tiles_per_xcd > 0) t = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
     if (t >= ntiles) return;
@@ -763,7 +772,8 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_reg(int64_t m, int64_t ntile
         for (int u = 0; u < NNZ; ++u) {
             const int uu = u < last ? u : last;
             const double av = t_val[base + uu];
-            const unsigned off = (unsigned)t_lcol[base + uu] * KC + 2 * part;
+            const unsigned lp = (unsigned)t_lcol[base + uu];
+            const unsigned off = lp * KC + 2 * part + (V2 == 2 ? ((lp >> 1) & 1u) * 8u : 0u); // vector 0; vector 1 is off ^ 8
             a[u] = (u < cnt) ? av : 0.0;
             if (u & 1)
                 xo2[u / 2] |= off << 16;
@@ -781,13 +791,15 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_reg(int64_t m, int64_t ntile
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         int idx = tid + 256 * i;
-        int f = idx / LPR;
+        int f = idx / SPR;
+        const int q = idx % SPR;
         f = f < nf ? f : 0;
         const int32_t c = fp[f0 + f];
         const unsigned ghost = (c < m) ? 0u : 0x80000000u;
         const unsigned eo = ghost ? (unsigned)((int64_t)(c - m) * ldg) : (unsigned)((int64_t)c * ldx);
-        soff[i] = (eo + 2 * part) | ghost;
-        const unsigned d = (unsigned)fpos[f0 + f] * KC + 2 * part;
+        soff[i] = (eo + 2 * q) | ghost;
+        const unsigned lp = (unsigned)fpos[f0 + f];
+        const unsigned d = lp * KC + (V2 == 2 ? (((unsigned)(q / 4) ^ ((lp >> 1) & 1u)) * 8u + 2u * (q % 4)) : 2u * q);
         if (i & 1)
             dst2[i / 2] |= d << 16;
         else
@@ -803,7 +815,7 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_reg(int64_t m, int64_t ntile
     const int lastc = (nchunks - 1) * KC;
 #pragma unroll
     for (int i = 0; i < NL; ++i) stage0[i] = *reinterpret_cast<const double2_t *>(RAILS_SRC(i));
-    {
+    if (NS == 2) {
         const int c1 = KC < lastc ? KC : lastc;
 #pragma unroll
         for (int i = 0; i < NL; ++i) stage1[i] = *reinterpret_cast<const double2_t *>(RAILS_SRC(i) + c1);
@@ -813,30 +825,41 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_reg(int64_t m, int64_t ntile
         const int ci__ = (CI);                                                                          \
         double *Xs = smem + (size_t)(ci__ & 1) * xs_doubles;                                            \
         _Pragma("unroll") for (int i = 0; i < NL; ++i) *reinterpret_cast<double2_t *>(&Xs[RAILS_DST(i)]) = STAGE[i]; \
-        const int cn__ = (ci__ + 2) * KC < lastc ? (ci__ + 2) * KC : lastc;                             \
+        const int cn__ = (ci__ + NS) * KC < lastc ? (ci__ + NS) * KC : lastc;                           \
         _Pragma("unroll") for (int i = 0; i < NL; ++i) STAGE[i] = *reinterpret_cast<const double2_t *>(RAILS_SRC(i) + cn__); \
         __syncthreads();                                                                                \
-        double2_t acc = (double2_t){0.0, 0.0};                                                          \
+        double2_t acc[V2];                                                                              \
+        _Pragma("unroll") for (int v = 0; v < V2; ++v) acc[v] = (double2_t){0.0, 0.0};                  \
         _Pragma("unroll") for (int u = 0; u < NNZ; ++u)                                                 \
         {                                                                                               \
             const unsigned off = (u & 1) ? (xo2[u / 2] >> 16) : (xo2[u / 2] & 0xffffu);                 \
-            const double2_t x = *reinterpret_cast<const double2_t *>(&Xs[off]);                         \
-            acc.x = __builtin_fma(a[u], x.x, acc.x);                                                    \
-            acc.y = __builtin_fma(a[u], x.y, acc.y);                                                    \
+            _Pragma("unroll") for (int v = 0; v < V2; ++v)                                              \
+            {                                                                                           \
+                const double2_t x = *reinterpret_cast<const double2_t *>(&Xs[v ? (off ^ 8u) : off]);    \
+                acc[v].x = __builtin_fma(a[u], x.x, acc[v].x);                                          \
+                acc[v].y = __builtin_fma(a[u], x.y, acc[v].y);                                          \
+            }                                                                                           \
         }                                                                                               \
-        const int cidx = ci__ * KC + 2 * part;                                                          \
-        if (cnt == 0) acc = (double2_t){0.0, 0.0};                                                      \
-        if (has_row) {                                                                                  \
-            double *dst = Y + yrow * ldy + cidx;                                                        \
-            if (cidx + 1 < nc)                                                                          \
-                *reinterpret_cast<double2_t *>(dst) = acc;                                              \
-            else if (cidx < nc)                                                                         \
-                *dst = acc.x;                                                                           \
+        _Pragma("unroll") for (int v = 0; v < V2; ++v)                                                  \
+        {                                                                                               \
+            const int cidx = ci__ * KC + v * 2 * LPR + 2 * part;                                        \
+            if (cnt == 0) acc[v] = (double2_t){0.0, 0.0};                                               \
+            if (has_row) {                                                                              \
+                double *dst = Y + yrow * ldy + cidx;                                                    \
+                if (cidx + 1 < nc)                                                                      \
+                    *reinterpret_cast<double2_t *>(dst) = acc[v];                                       \
+                else if (cidx < nc)                                                                     \
+                    *dst = acc[v].x;                                                                    \
+            }                                                                                           \
         }                                                                                               \
     } while (0)
-    for (int ci = 0; ci < nchunks; ci += 2) {
-        RAILS_TILE_STEP(stage0, ci);
-        if (ci + 1 < nchunks) RAILS_TILE_STEP(stage1, ci + 1);
+    if (NS == 2) {
+        for (int ci = 0; ci < nchunks; ci += 2) {
+            RAILS_TILE_STEP(stage0, ci);
+            if (ci + 1 < nchunks) RAILS_TILE_STEP(stage1, ci + 1);
+        }
+    } else {
+        for (int ci = 0; ci < nchunks; ++ci) RAILS_TILE_STEP(stage0, ci);
     }
 #undef RAILS_TILE_STEP
 #undef RAILS_SRC
@@ -1131,33 +1154,45 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
     // rounded-up last chunk, and ghost rows (stored with ld = nc) must be a whole number of chunks
     const bool full_width_ok = ((nc + KC - 1) / KC * KC <= x_room) && (A->n_ghost == 0 || nc % KC == 0);
     {
-        const int lpr_r = KC / 2;
-        const int need_nl_r = (A->max_fp * lpr_r + 255) / 256;
-        const size_t lds_reg = 2 * (size_t)xs_doubles * 8;
-        if (env_reg && full_width_ok && xs_doubles < 65536 && (int64_t)A->m * ldx < 0x7fffffffLL && (int64_t)(A->n_ghost + 1) * ldg < 0x7fffffffLL && A->tile_rows <= 256 / lpr_r && A->max_row_nnz <= 32 && need_nl_r <= 8 && lds_reg <= (size_t)lds_budget) {
+        // wide chunks (16 columns, 4 lanes x 32 B per row) for wide panels; narrow panels keep two 8-column chunks in flight
+        // (measured on MI355X: not faster than 8-column chunks -- 0.82 vs 0.79 ms on the 27-point stencil at nc = 128; both forms
+        // move ~10 B/clk/CU through the load path, which is what bounds this kernel: profiles/r01_spmm_tiled_wide.md -- so it
+        // is off unless asked for: operator variant 6 or RAILS_SPMM_TILE_WIDE=1)
+        static const int env_wide = spmm_env("RAILS_SPMM_TILE_WIDE", 0);
+        const bool wide = (env_wide || A->variant == 6) && nc >= 32 && ((nc + 15) / 16 * 16 <= x_room) && (A->n_ghost == 0 || nc % 16 == 0);
+        const int KCr = wide ? 16 : KC, V2r = wide ? 2 : 1;
+        const int lpr_r = KCr / (2 * V2r);
+        const int need_nl_r = (A->max_fp * (KCr / 2) + 255) / 256;
+        const int xs_r = A->max_pos * KCr;
+        const size_t lds_reg = 2 * (size_t)xs_r * 8;
+        if (env_reg && (wide || full_width_ok) && xs_r < 65536 && (int64_t)A->m * ldx < 0x7fffffffLL && (int64_t)(A->n_ghost + 1) * ldg < 0x7fffffffLL && A->tile_rows <= 256 / lpr_r && A->max_row_nnz <= 32 && need_nl_r <= 8 && lds_reg <= (size_t)lds_budget) {
             const int nnz4 = (A->max_row_nnz + 3) / 4;
-#define RAILS_REG_ARGS A->m, A->n_tiles, A->t_rowptr, A->t_rows, A->t_nzptr, A->t_rp, A->t_val, A->t_lcol, A->t_fp_ptr, A->t_fp, A->t_fpos, X, ldx, Xg, ldg, Y, ldy, nc, tpx, xs_doubles
-#define RAILS_LAUNCH_REG(KCV, NNZV, NLV)                                                                                              \
+#define RAILS_REG_ARGS A->m, A->n_tiles, A->t_rowptr, A->t_rows, A->t_nzptr, A->t_rp, A->t_val, A->t_lcol, A->t_fp_ptr, A->t_fp, A->t_fpos, X, ldx, Xg, ldg, Y, ldy, nc, tpx, xs_r
+// two chunks in flight unless that needs more than 256 VGPRs (wide chunks with long rows and 8 staging slots)
+#define RAILS_LAUNCH_REG(KCV, NNZV, NLV, V2V)                                                                                         \
     do {                                                                                                                               \
-        RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled_reg<KCV, NNZV, NLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg)); \
-        hipLaunchKernelGGL((k_spmm_tiled_reg<KCV, NNZV, NLV>), dim3((unsigned)grid), dim3(256), lds_reg, c->stream, RAILS_REG_ARGS); \
+        constexpr int NSV = (V2V == 2 && NNZV * 2 + NLV * 8 > 100) ? 1 : 2;                                                           \
+        RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled_reg<KCV, NNZV, NLV, V2V, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg)); \
+        hipLaunchKernelGGL((k_spmm_tiled_reg<KCV, NNZV, NLV, V2V, NSV>), dim3((unsigned)grid), dim3(256), lds_reg, c->stream, RAILS_REG_ARGS); \
     } while (0)
-#define RAILS_REG_NL(KCV, NNZV)                                  \
+#define RAILS_REG_NL(KCV, NNZV, V2V)                             \
     do {                                                         \
-        if (need_nl_r <= 4) RAILS_LAUNCH_REG(KCV, NNZV, 4);      \
-        else RAILS_LAUNCH_REG(KCV, NNZV, 8);                     \
+        if (need_nl_r <= 4) RAILS_LAUNCH_REG(KCV, NNZV, 4, V2V); \
+        else RAILS_LAUNCH_REG(KCV, NNZV, 8, V2V);                \
     } while (0)
-#define RAILS_REG_NNZ(KCV)                                       \
+#define RAILS_REG_NNZ(KCV, V2V)                                  \
     do {                                                         \
-        if (nnz4 <= 2) RAILS_REG_NL(KCV, 8);                     \
-        else if (nnz4 <= 4) RAILS_REG_NL(KCV, 16);               \
-        else if (nnz4 <= 7) RAILS_REG_NL(KCV, 28);               \
-        else RAILS_REG_NL(KCV, 32);                              \
+        if (nnz4 <= 2) RAILS_REG_NL(KCV, 8, V2V);                \
+        else if (nnz4 <= 4) RAILS_REG_NL(KCV, 16, V2V);          \
+        else if (nnz4 <= 7) RAILS_REG_NL(KCV, 28, V2V);          \
+        else RAILS_REG_NL(KCV, 32, V2V);                         \
     } while (0)
-            if (KC == 8)
-                RAILS_REG_NNZ(8);
+            if (wide)
+                RAILS_REG_NNZ(16, 2);
+            else if (KC == 8)
+                RAILS_REG_NNZ(8, 1);
             else
-                RAILS_REG_NNZ(16);
+                RAILS_REG_NNZ(16, 1);
 #undef RAILS_REG_NNZ
 #undef RAILS_REG_NL
 #undef RAILS_LAUNCH_REG

@@ -107,9 +107,11 @@ def test_spmm_matches_oracle(ctx, oracle, name):
             np.testing.assert_allclose(YT.to_host(), dense.T @ Xh, atol=1e-13 * scale * nnz_row)
 
 
+@pytest.mark.parametrize("variant", [2, 6])
 @pytest.mark.parametrize("name", ["laplace7_small", "stencil27_rand", "banded"])
-def test_spmm_lds_staged_kernel_matches_oracle(ctx, oracle, name):
-    """variant 2 = LDS-staged footprint kernel (k_spmm_tiled); bit-for-bit the same sums in the same order per row."""
+def test_spmm_lds_staged_kernel_matches_oracle(ctx, oracle, name, variant):
+    """variant 2 = LDS-staged footprint kernel (k_spmm_tiled*), 6 = the same with 16-column chunks; the same sums in the same
+    order per row as the row-gather kernel."""
     import rails_amd
     from rails_amd import problems as P
 
@@ -117,7 +119,7 @@ def test_spmm_lds_staged_kernel_matches_oracle(ctx, oracle, name):
          "banded": P.banded_random(5000, 27, 40, seed=1)}[name]
     m = A[0].size - 1
     op = rails_amd.HipOperatorWrapper(ctx, *A)
-    op.set_variant(2)
+    op.set_variant(variant)
     g = np.random.default_rng(13)
     for nc, xoff, yoff in ((8, 0, 0), (16, 16, 0), (17, 0, 2), (64, 2, 0), (128, 0, 0), (130, 0, 0)):
         Xh = g.uniform(-1, 1, (m, nc))
