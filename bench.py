@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--projected-lanczos", type=int, default=0, help="1: coefficient-space residual Lanczos (rails/HipSolverOps.hpp)")
     ap.add_argument("--spmm-only", action="store_true", help="kernel experiment: only the A*X timing, for several column counts")
     ap.add_argument("--spmm-cols", default="128", help="comma list of column counts for --spmm-only")
+    ap.add_argument("--spmm-pad", type=int, default=0, help="--spmm-only: extra panel capacity (columns), i.e. a row stride that is not a power of two")
     args = ap.parse_args()
 
     import torch
@@ -144,8 +145,8 @@ def main():
 
     if args.spmm_only:
         for kk in [int(x) for x in args.spmm_cols.split(",")]:
-            X = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk)
-            Y = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk)
+            X = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk + args.spmm_pad)
+            Y = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk + args.spmm_pad)
             X.random()
             for variant in ((1, 2) if args.spmm_variant == 0 else (args.spmm_variant,)):
                 A.set_variant(variant)
@@ -161,7 +162,7 @@ def main():
                     A.apply(X, Y)
                 ms = ctx.timer_stop() / args.spmm_reps
                 ab = nnz_local * 12 + (ml + 1) * 4 + 2 * ml * kk * 8
-                print(json.dumps({"pattern": args.pattern, "kernel": A.last_kernel(), "variant": variant, "k": kk, "ms": ms,
+                print(json.dumps({"pattern": args.pattern, "kernel": A.last_kernel(), "variant": variant, "k": kk, "pad": args.spmm_pad, "ms": ms,
                                   "alg_GBs": ab / ms / 1e6, "frac": ab / ms / 1e6 / HBM_PEAK_GBS}), flush=True)
             del X, Y
         return
