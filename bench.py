@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--force-hooks", action="store_true", help="single rank: still route every reduction through torch.distributed (RCCL, world size 1)")
     ap.add_argument("--projected-lanczos", type=int, default=0, help="1: coefficient-space residual Lanczos (rails/HipSolverOps.hpp)")
+    ap.add_argument("--subspace", type=int, default=0, help="1: coordinate-space back end (rails/SubspaceWrappers.hpp)")
     ap.add_argument("--spmm-only", action="store_true", help="kernel experiment: only the A*X timing, for several column counts")
     ap.add_argument("--spmm-cols", default="128", help="comma list of column counts for --spmm-only")
     ap.add_argument("--spmm-pad", type=int, default=0, help="--spmm-only: extra panel capacity (columns), i.e. a row stride that is not a power of two")
@@ -204,6 +205,7 @@ def main():
     solver.set_option("verbose", 1 if args.verbose else 0)
     solver.set_option("max_trips", W + K)
     solver.set_option("projected_lanczos", args.projected_lanczos)
+    solver.set_option("subspace", args.subspace)
     marks = {}
 
     def on_trip(trip):
@@ -225,7 +227,7 @@ def main():
     its = K / elapsed
     hist = solver.history()
     log("[rank %d] host sections (s, whole solve incl. warm-up): %s" % (rank, json.dumps(solver.profile())))
-    log("[rank %d] counters: %s" % (rank, json.dumps(ctx.stats())))
+    log("[rank %d] counters: %s %s" % (rank, json.dumps(ctx.stats()), json.dumps(solver.backend_stats())))
     log("[rank %d] %d trips in %.3fs -> %.2f it/s; Lanczos estimates %.3e -> %.3e; V.N()=%d" % (rank, K, elapsed, its, hist[0], hist[-1], solver.k))
 
     # ---- cpu_baseline: the oracle (port of the Stl path) on a bounded sample, rank 0, N = 1 ---------------
@@ -271,7 +273,8 @@ def main():
             "config": {"workload": "BASELINE configs[2]: m=%d rows/GPU (global %d), 27 nnz/row %s CSR, B m x %d, Restart size %d, Reduced size %d, "
                                    "Expand size %d, Lanczos iterations %d" % (ml, mg, desc, args.p, args.restart, args.reduced, args.expand, args.lanczos),
                        "parallelism": "row-partition x%d, RCCL all-reduce of projected blocks" % nranks if nranks > 1 else "single GPU",
-                       "spmm_columns": kk, "residual_lanczos": "projected" if args.projected_lanczos else "fused"},
+                       "spmm_columns": kk, "residual_lanczos": "projected" if args.projected_lanczos else "fused",
+                       "backend": "coordinates in a device-resident orthonormal basis" if args.subspace else "direct panels"},
             "roofline": {"bound": "hbm", "kernel": spmm_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms},
             "cpu_baseline": cpu,

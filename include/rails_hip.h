@@ -220,6 +220,9 @@ void rails_dpotrf(char uplo, int n, double *a, int lda, int *info);
 /* Cholesky with complete pivoting of a positive semi-definite matrix (LAPACK dpstrf): P'AP = R'R, stops at the first pivot
  * <= tol; *rank = pivots taken, piv 0-based (column j of the factor belongs to column piv[j] of A); info 1 = rank < n. */
 void rails_dpstrf(char uplo, int n, double *a, int lda, int *piv, int *rank, double tol, int *info);
+/* Orthonormal basis of the column space of A (m x n, overwritten): pivoted Householder QR (dgeqp3 + dorgqr), rank = pivots with
+ * |r_ii| > tol*|r_11|; q (m x rank, ldq >= m).  info = -100 when the host LAPACK lacks dgeqp3/dorgqr. */
+void rails_range_basis(int m, int n, double *a, int lda, double tol, double *q, int ldq, int *rank, int *info);
 int rails_host_lapack_init(const char *path);
 const char *rails_host_lapack_path(void);
 

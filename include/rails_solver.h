@@ -33,7 +33,9 @@ int rails_solver_set_parameter(rails_solver *s, const char *name, double value);
 int rails_solver_apply_parameters(rails_solver *s, int *code);
 
 /* extensions: "mass" (use M, generalized equation), "verbose", "max_trips", "projected_lanczos" (M = I only: carry the
- * residual Lanczos recurrence in coefficient space, see rails/HipSolverOps.hpp) */
+ * residual Lanczos recurrence in coefficient space, see rails/HipSolverOps.hpp), "subspace" (M = I, cold start: run the same solver
+ * template on the coordinate-space back end of rails/SubspaceWrappers.hpp -- all multivectors as coordinates in one orthonormal
+ * device basis) */
 int rails_solver_set_option(rails_solver *s, const char *name, double value);
 /* called at the start of every loop trip with the index of that trip, and once after the last */
 typedef void (*rails_trip_fn)(void *user, int trip);
@@ -54,6 +56,8 @@ int rails_solver_history(rails_solver *s, double *res, int cap);      /* Lanczos
 /* host wall-clock seconds per solver section of the last solve (JSON object; names follow the reference's profile
  * sections, src/Timer.hpp:101-106: "Apply A", "Apply B", "Compute VAV", "dense_solve", "Residual Lanczos", ...) */
 int rails_solver_profile(rails_solver *s, char *buf, int cap);
+/* JSON counters of the coordinate-space back end for the last solve ("{}" when the direct back end ran). */
+const char *rails_solver_backend_stats(rails_solver *s);
 
 /* ||A X + X A' + B B'||_F / ||B B'||_F for X = V T V' evaluated on the device without forming X
  * (uses R = [AV V B] G [AV V B]'; test / reporting helper) */

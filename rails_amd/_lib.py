@@ -70,6 +70,7 @@ SIGNATURES = {
     "rails_dgemm": (None, [C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int]),
     "rails_dpotrf": (None, [C.c_char, C.c_int, _dp, C.c_int, _ip]),
     "rails_dpstrf": (None, [C.c_char, C.c_int, _dp, C.c_int, _ip, _ip, C.c_double, _ip]),
+    "rails_range_basis": (None, [C.c_int, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int, _ip, _ip]),
     "rails_host_lapack_init": (C.c_int, [C.c_char_p]),
     "rails_host_lapack_path": (C.c_char_p, []),
 }

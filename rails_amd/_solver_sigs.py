@@ -22,6 +22,7 @@ SOLVER_SIGNATURES = {
     "rails_solver_history": (C.c_int, [_vp, _dp, C.c_int]),
     "rails_solver_relative_residual": (C.c_int, [_vp, _dp]),
     "rails_solver_profile": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "rails_solver_backend_stats": (C.c_char_p, [_vp]),
 }
 
 

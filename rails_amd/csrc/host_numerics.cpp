@@ -31,6 +31,8 @@ typedef void (*lp_dgees)(const char *, const char *, lp_select2, const int *, do
 typedef void (*lp_dtrsyl)(const char *, const char *, const int *, const int *, const int *, const double *, const int *,
                           const double *, const int *, double *, const int *, double *, int *);
 typedef void (*lp_dpotrf)(const char *, const int *, double *, const int *, int *);
+typedef void (*lp_dgeqp3)(const int *, const int *, double *, const int *, int *, double *, double *, const int *, int *);
+typedef void (*lp_dorgqr)(const int *, const int *, const int *, double *, const int *, const double *, double *, const int *, int *);
 typedef void (*lp_dpstrf)(const char *, const int *, double *, const int *, int *, int *, const double *, double *, int *);
 typedef void (*lp_dgemm)(const char *, const char *, const int *, const int *, const int *, const double *, const double *,
                          const int *, const double *, const int *, const double *, double *, const int *);
@@ -45,6 +47,8 @@ struct HostLapack {
     lp_dtrsyl dtrsyl = nullptr;
     lp_dpotrf dpotrf = nullptr;
     lp_dpstrf dpstrf = nullptr; // optional
+    lp_dgeqp3 dgeqp3 = nullptr; // optional (rails_range_basis)
+    lp_dorgqr dorgqr = nullptr;
     lp_dgemm dgemm = nullptr;
 } g_lp;
 std::mutex g_lp_mutex;
@@ -74,6 +78,8 @@ bool try_open(const std::string &path)
     L.dpotrf = (lp_dpotrf)lookup(h, "dpotrf_");
     L.dgemm = (lp_dgemm)lookup(h, "dgemm_");
     L.dpstrf = (lp_dpstrf)lookup(h, "dpstrf_");
+    L.dgeqp3 = (lp_dgeqp3)lookup(h, "dgeqp3_");
+    L.dorgqr = (lp_dorgqr)lookup(h, "dorgqr_");
     if (!L.dsyev || !L.dsteqr || !L.dgees || !L.dtrsyl || !L.dpotrf || !L.dgemm) {
         dlclose(h);
         return false;
@@ -223,6 +229,47 @@ extern "C" void rails_dpstrf(char uplo, int n, double *a, int lda, int *piv, int
     }
     *rank = r;
     *info = r < n ? 1 : 0;
+}
+
+// Orthonormal basis of the column space of A (m x n, column-major, overwritten): Householder QR with column pivoting (dgeqp3),
+// numerical rank = pivots with |r_ii| > tol * |r_11|, Q (m x rank) formed with dorgqr into q (ldq >= m).  Used by the
+// coordinate-space backend (rails/SubspaceWrappers.hpp) to compress its basis after a restart.
+extern "C" void rails_range_basis(int m, int n, double *a, int lda, double tol, double *q, int ldq, int *rank, int *info)
+{
+    *rank = 0;
+    if (rails_host_lapack_init(nullptr) != RAILS_OK || !g_lp.dgeqp3 || !g_lp.dorgqr) {
+        *info = -100;
+        return;
+    }
+    if (m <= 0 || n <= 0) {
+        *info = 0;
+        return;
+    }
+    const int kmin = m < n ? m : n;
+    std::vector<int> jpvt((size_t)n, 0);
+    std::vector<double> tau((size_t)kmin);
+    double wq = 0.0;
+    int lwork = -1;
+    g_lp.dgeqp3(&m, &n, a, &lda, jpvt.data(), tau.data(), &wq, &lwork, info);
+    if (*info != 0) return;
+    lwork = (int)wq + 1;
+    std::vector<double> work((size_t)lwork);
+    g_lp.dgeqp3(&m, &n, a, &lda, jpvt.data(), tau.data(), work.data(), &lwork, info);
+    if (*info != 0) return;
+    const double r11 = std::fabs(a[0]);
+    int r = 0;
+    while (r < kmin && std::fabs(a[r + (size_t)r * lda]) > tol * r11 && r11 > 0.0) ++r;
+    *rank = r;
+    if (r == 0) return;
+    // the reflectors live below the diagonal of a's first r columns: copy them to q and expand
+    for (int j = 0; j < r; ++j)
+        for (int i = 0; i < m; ++i) q[i + (size_t)j * ldq] = a[i + (size_t)j * lda];
+    lwork = -1;
+    g_lp.dorgqr(&m, &r, &r, q, &ldq, tau.data(), &wq, &lwork, info);
+    if (*info != 0) return;
+    lwork = (int)wq + 1;
+    work.resize((size_t)lwork);
+    g_lp.dorgqr(&m, &r, &r, q, &ldq, tau.data(), work.data(), &lwork, info);
 }
 
 // Continuous-time Lyapunov equation, SB03MD('C','X','N',trans):

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "rails/HipSolverOps.hpp"
+#include "rails/SubspaceWrappers.hpp"
 #include "rails_solver.h"
 
 void rails_set_error(const char *fmt, ...);
@@ -45,6 +46,15 @@ struct rails_solver {
     bool mass = false;
     rails_trip_fn trip_fn = nullptr;
     void *trip_user = nullptr;
+    // coordinate-space back end (rails/SubspaceWrappers.hpp): used by solve() when asked for and applicable
+    bool subspace = false, verbose = true, projected = false;
+    int max_trips = 0;
+    bool have_V0 = false;
+    bool last_was_subspace = false;
+    int sub_trips = 0;
+    std::vector<double> sub_hist;
+    std::map<std::string, double> sub_profile;
+    std::string sub_stats;
 };
 
 extern "C" int rails_solver_create(rails_ctx *ctx, rails_csr *A, rails_csr *M, const double *B_host, int64_t ldb, int p, int64_t m_global,
@@ -114,12 +124,17 @@ extern "C" int rails_solver_set_option(rails_solver *s, const char *name, double
         }
         s->mass = value != 0.0;
         s->solver->use_mass_matrix(s->mass);
-    } else if (n == "verbose")
-        s->solver->set_verbose(value != 0.0);
-    else if (n == "max_trips")
-        s->solver->set_max_trips((int)value);
-    else if (n == "projected_lanczos")
-        s->solver->set_projected_lanczos(value != 0);
+    } else if (n == "verbose") {
+        s->verbose = value != 0.0;
+        s->solver->set_verbose(s->verbose);
+    } else if (n == "max_trips") {
+        s->max_trips = (int)value;
+        s->solver->set_max_trips(s->max_trips);
+    } else if (n == "projected_lanczos") {
+        s->projected = value != 0;
+        s->solver->set_projected_lanczos(s->projected);
+    } else if (n == "subspace")
+        s->subspace = value != 0;
     else {
         rails_set_error("rails_solver_set_option: unknown option '%s'", name);
         return RAILS_EINVAL;
@@ -149,13 +164,55 @@ extern "C" int rails_solver_set_V(rails_solver *s, const double *V_host, int64_t
     s->V.set_global_rows(s->m_global);
     s->V.from_host(V_host, ldv);
     s->V.set_orthogonalized(k); // the caller's V is assumed orthonormal
+    s->have_V0 = true;
     return RAILS_OK;
+}
+
+// the same solve on the coordinate-space back end: B and every later vector are expressed in one orthonormal device basis
+static int solve_in_coordinates(rails_solver *s)
+{
+    const int p = s->B.N();
+    const int restart = s->params.get("Restart size", -1);
+    const int expand = s->params.get("Expand size", 3);
+    const int kmax = std::max(restart > 0 ? restart : 100, 1) + expand + 100;
+    auto basis = std::make_shared<rails::SubspaceBasis>(s->ctx, s->m_local, s->m_global, 2 * kmax + p + 128);
+    rails::SubspaceMultiVector Bc = rails::SubspaceMultiVector::Absorb(basis, s->B);
+    rails::SubspaceOperator Ac(s->A, basis);
+    rails::SubspaceSolver solver(Ac, Bc, Ac);
+    int prc = solver.set_parameters(s->params);
+    if (prc != 0) return prc + 100;
+    solver.set_verbose(s->verbose);
+    solver.set_max_trips(s->max_trips);
+    if (s->trip_fn) solver.set_trip_callback([s](int trip) { s->trip_fn(s->trip_user, trip); });
+    rails::SubspaceMultiVector Vc(basis, 1);
+    int rc = solver.solve(Vc, s->T);
+    s->V = Vc.materialise();
+    s->V.set_orthogonalized(s->V.N());
+    s->sub_trips = solver.trips();
+    s->sub_hist = solver.residual_history();
+    s->sub_profile = solver.profile();
+    char buf[256];
+    snprintf(buf, sizeof(buf), "{\"dim\": %d, \"absorb\": %ld, \"absorb_columns\": %ld, \"one_by_one\": %ld, \"dropped\": %ld, \"compress\": %ld, \"materialise\": %ld}",
+             basis->dim, basis->n_absorb, basis->n_absorb_cols, basis->n_single, basis->n_dropped, basis->n_compress, basis->n_materialise);
+    s->sub_stats = buf;
+    if (basis->failed) {
+        rails_set_error("coordinate-space back end: a device operation failed (%s)", rails_last_error());
+        return -1000;
+    }
+    return rc;
 }
 
 extern "C" int rails_solver_solve(rails_solver *s, int *code, int *k)
 {
     if (!s) return RAILS_EINVAL;
-    int rc = s->solver->solve(s->V, s->T);
+    const bool restart_from_solution = s->params.get("Restart from solution", 0.0) != 0.0;
+    s->last_was_subspace = s->subspace && !s->mass && !s->have_V0 && !restart_from_solution;
+    int rc;
+    if (s->last_was_subspace) {
+        rc = solve_in_coordinates(s);
+        if (rc == -1000) return RAILS_EHIP;
+    } else
+        rc = s->solver->solve(s->V, s->T);
     if (code) *code = rc;
     if (k) *k = s->V.N();
     if (rails_ctx_sync(s->ctx) != RAILS_OK) return RAILS_EHIP;
@@ -179,12 +236,14 @@ extern "C" int rails_solver_get_T(rails_solver *s, double *T_host, int ldt)
     return RAILS_OK;
 }
 
-extern "C" int rails_solver_trips(rails_solver *s) { return s ? s->solver->trips() : -1; }
+extern "C" int rails_solver_trips(rails_solver *s) { return s ? (s->last_was_subspace ? s->sub_trips : s->solver->trips()) : -1; }
+
+extern "C" const char *rails_solver_backend_stats(rails_solver *s) { return (s && s->last_was_subspace) ? s->sub_stats.c_str() : "{}"; }
 
 extern "C" int rails_solver_history(rails_solver *s, double *res, int cap)
 {
     if (!s) return -1;
-    auto const &h = s->solver->residual_history();
+    auto const &h = s->last_was_subspace ? s->sub_hist : s->solver->residual_history();
     int n = (int)h.size();
     for (int i = 0; i < n && i < cap; ++i) res[i] = h[i];
     return n;
@@ -195,7 +254,7 @@ extern "C" int rails_solver_profile(rails_solver *s, char *buf, int cap)
     if (!s || !buf || cap < 2) return RAILS_EINVAL;
     std::string out = "{";
     bool first = true;
-    for (auto const &kv : s->solver->profile()) {
+    for (auto const &kv : (s->last_was_subspace ? s->sub_profile : s->solver->profile())) {
         char tmp[256];
         snprintf(tmp, sizeof(tmp), "%s\"%s\": %.6f", first ? "" : ", ", kv.first.c_str(), kv.second);
         out += tmp;

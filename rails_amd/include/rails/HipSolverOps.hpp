@@ -113,7 +113,7 @@ struct SolverOps<HipOperatorWrapper, HipMultiVectorWrapper, HostDenseMatrix> {
         return AV.view(n, n + wn - 1);
     }
 
-    static void on_restart(State &st, HostDenseMatrix const &X)
+    static void on_restart(State &st, HostDenseMatrix const &X, HipMultiVectorWrapper &, HipMultiVectorWrapper &)
     {
         if (st.kc <= 0 || X.M() != st.kc) { // nothing cached (or inconsistent): recompute from scratch next time
             st.kc = 0;

@@ -88,6 +88,8 @@ public:
     int M() const { return transpose_ ? n_ : m_; }
     int N() const { return transpose_ ? m_ : n_; }
     int LDA() const { return transpose_ ? n_max_ : m_max_; }
+    bool transposed() const { return transpose_; } // storage is that of the un-transposed matrix, leading dimension raw_ld()
+    int raw_ld() const { return m_max_; }
 
     // resize keeps contents and, within capacity, the leading dimension (src/StlWrapper.cpp:225-263)
     void resize(int m, int n)

@@ -177,7 +177,8 @@ struct SolverOps {
         return solver.resid_lanczos(AV, MV, T, H, out.eigenvectors, out.eigenvalues, max_iter);
     }
 
-    static void on_restart(State &, DenseMatrix const &) {}
+    // after V <- V X and AV <- AV X of a restart (:265-291)
+    static void on_restart(State &, DenseMatrix const &, MultiVector &, MultiVector &) {}
 
     // V <- V * X (first X.N() columns), as `V.view(0, X.N()-1) = V * X; V.resize(X.N())`   (:265-266)
     static void multiply_inplace(MultiVector &V, DenseMatrix const &X)
@@ -411,7 +412,7 @@ public:
                 VAV.view() = tmp;
 
                 Ops::multiply_inplace(AV, X); // :290-291
-                Ops::on_restart(ops_state_, X);
+                Ops::on_restart(ops_state_, X, V, AV);
 
                 tmp = X.transpose() * (VBV * X); // :293-295
                 VBV.resize(X.N(), X.N());

@@ -1,0 +1,739 @@
+// SubspaceWrappers.hpp -- a second HIP back end for Solver<Matrix, MultiVector, DenseMatrix>: multivectors held as COORDINATES in
+// an orthonormal basis P that lives on the device.
+//
+// Every vector the RAILS loop ever forms lies in span[B, random start vectors, A*(earlier vectors)].  This back end keeps ONE
+// orthonormal basis P (m x dim, row-partitioned device panel) of that span and represents every multivector by its dim x n
+// coefficient matrix on the host (replicated on every rank).  Then
+//   * dot, norm, axpy, scale, `* DenseMatrix`, views, orthogonalize() -- everything the solver and its residual Lanczos do
+//     between two operator applications -- are small host operations on coefficients (exact images of the reference's
+//     m-dimensional operations, because P is orthonormal);
+//   * device work happens only where NEW directions enter: `A * W` (materialise W = P*Wc, CSR SpMM straight into P's tail,
+//     orthonormalise the tail against P: block CGS2 + CholQR2, coefficients by bookkeeping) and `random()` (fill, project);
+//   * after a restart the live coefficient matrices span fewer directions than P holds: compress() re-bases P on an
+//     orthonormal basis of their column space (pivoted Householder QR on the host, one panel GEMM on the device).
+// Per RAILS trip that is ~8 passes over the m x dim basis instead of the 21 passes over [AV V B] of the fused Lanczos kernel
+// plus the projection / orthogonalisation passes of the direct back end (HipWrappers.hpp), and ~8 all-reduces instead of ~31.
+//
+// The classes satisfy the same duck-typed contract as HipMultiVectorWrapper / HipOperatorWrapper, so the
+// unmodified solver template -- the reference's member-by-member sequence, src/LyapunovSolver.hpp:100-482 -- runs on them.
+// Not covered: warm starts from a user V, mass matrices (the C API falls back to the direct back end).
+#ifndef RAILS_SUBSPACEWRAPPERS_HPP
+#define RAILS_SUBSPACEWRAPPERS_HPP
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <vector>
+
+#include "rails/HipWrappers.hpp"
+#include "rails/LyapunovSolver.hpp"
+
+namespace rails
+{
+
+// coefficient block: column-major, ld rows of capacity (rows past the basis dimension are zero), ncap columns
+struct CoefStore {
+    std::vector<double> c;
+    int ld = 0, ncap = 0;
+    bool in_basis = true; // false: a plain small replicated matrix with ld rows (B'W and friends)
+    CoefStore(int ld_, int ncap_, bool in_basis_) : c((size_t)std::max(ld_, 1) * std::max(ncap_, 1), 0.0), ld(ld_), ncap(std::max(ncap_, 1)), in_basis(in_basis_) {}
+    double *col(int j) { return c.data() + (size_t)j * ld; }
+    const double *col(int j) const { return c.data() + (size_t)j * ld; }
+};
+
+class SubspaceBasis
+{
+public:
+    rails_ctx *ctx;
+    int64_t m_local, m_global;
+    HipMultiVectorWrapper P, P2; // basis panel and the ping-pong panel used by compress()
+    int dim = 0;
+    int row_cap; // leading dimension of every coefficient store
+    std::vector<std::weak_ptr<CoefStore>> live;
+    long n_absorb = 0, n_absorb_cols = 0, n_single = 0, n_compress = 0, n_materialise = 0, n_dropped = 0;
+    bool failed = false;
+
+    SubspaceBasis(rails_ctx *c, int64_t ml, int64_t mg, int rows) : ctx(c), m_local(ml), m_global(mg), P(ml, std::max(rows, 16), c), row_cap(std::max(rows, 16))
+    {
+        P.set_global_rows(mg);
+        P.resize(0);
+    }
+
+    std::shared_ptr<CoefStore> new_store(int ncap, bool in_basis, int rows = 0)
+    {
+        auto s = std::make_shared<CoefStore>(in_basis ? row_cap : rows, ncap, in_basis);
+        if (in_basis) live.push_back(s);
+        return s;
+    }
+
+    void ensure_rows(int need)
+    {
+        if (need <= row_cap) return;
+        int ncap = std::max(need + 64, row_cap + row_cap / 2);
+        for (auto &w : live)
+            if (auto s = w.lock()) {
+                std::vector<double> nc((size_t)ncap * s->ncap, 0.0);
+                for (int j = 0; j < s->ncap; ++j) memcpy(nc.data() + (size_t)j * ncap, s->col(j), sizeof(double) * dim);
+                s->c.swap(nc);
+                s->ld = ncap;
+            }
+        row_cap = ncap;
+    }
+
+    // P(:, 0:dim) * C  (C host, dim x n, ldc) -> new device multivector m x n
+    HipMultiVectorWrapper materialise(const double *C, int ldc, int n)
+    {
+        HipMultiVectorWrapper out(m_local, std::max(n, 1), ctx);
+        out.set_global_rows(m_global);
+        out.resize(n);
+        n_materialise++;
+        if (n <= 0) return out;
+        if (dim == 0) {
+            out = 0.0;
+            return out;
+        }
+        for (int j0 = 0; j0 < n; j0 += 256) {
+            int nc = std::min(256, n - j0);
+            if (!hip_ok(rails_panel_gemm(ctx, 1.0, P.panel(), 0, dim, C + (size_t)j0 * ldc, ldc, nc, 0.0, out.panel(), j0), "rails_panel_gemm")) failed = true;
+        }
+        return out;
+    }
+
+    // room for w more columns behind the basis; returns the first tail column
+    int tail(int w)
+    {
+        if (dim + w > P.capacity()) {
+            P.resize(dim); // reserve keeps the columns in use
+            P.resize(dim + w + 64);
+        }
+        P.resize(dim);
+        ensure_rows(dim + w);
+        return dim;
+    }
+
+    // The w columns X sitting in P's tail [dim, dim+w) are expressed in the basis: the part of X outside span(P) becomes new
+    // orthonormal basis columns, coef (row_cap x w, zero-initialised by the caller, ld = row_cap) receives the coordinates of X in
+    // the extended basis.  Block CGS2 against P, CholQR2 inside the block; the representation is X = P_old (C1 + C2) + Q (R2 R1).
+    bool absorb_tail(int w, double *coef)
+    {
+        n_absorb++;
+        n_absorb_cols += w;
+        if (w <= 0) return true;
+        const int ld = row_cap;
+        rails_panel *pp = P.panel();
+        std::vector<double> G0((size_t)w * w), C((size_t)std::max(dim, 1) * w), G((size_t)w * w);
+        if (!hip_ok(rails_gram(ctx, pp, dim, w, pp, dim, w, G0.data(), w), "rails_gram")) return fail();
+        bool second = true;
+        for (int round = 0; round < 2 && dim > 0; ++round) {
+            if (round == 1 && !second) break;
+            if (!hip_ok(rails_gram(ctx, pp, 0, dim, pp, dim, w, C.data(), dim), "rails_gram")) return fail();
+            if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, C.data(), dim, w, 1.0, pp, dim), "rails_panel_gemm")) return fail();
+            for (int j = 0; j < w; ++j)
+                for (int i = 0; i < dim; ++i) coef[i + (size_t)j * ld] += C[i + (size_t)j * dim];
+            if (round == 0 && w == 1) { // "twice is enough": a second projection only when the first one cancelled digits
+                double c2 = 0.0;
+                for (int i = 0; i < dim; ++i) c2 += C[i] * C[i];
+                second = !(c2 < 0.25 * G0[0]);
+            }
+        }
+        if (!hip_ok(rails_gram(ctx, pp, dim, w, pp, dim, w, G.data(), w), "rails_gram")) return fail();
+        // columns that (numerically) lie in span(P): nothing new to add
+        std::vector<int> keep;
+        for (int j = 0; j < w; ++j) {
+            if (G[j + (size_t)j * w] > 1e-26 * G0[j + (size_t)j * w] && G[j + (size_t)j * w] > 0.0)
+                keep.push_back(j);
+            else
+                n_dropped++;
+        }
+        const int r = (int)keep.size();
+        if (r == 0) return true;
+        // Cholesky of the diagonally scaled Gram matrix of the kept columns
+        std::vector<double> d(r), S((size_t)r * r);
+        for (int a = 0; a < r; ++a) d[a] = std::sqrt(G[keep[a] + (size_t)keep[a] * w]);
+        for (int b = 0; b < r; ++b)
+            for (int a = 0; a < r; ++a) S[a + (size_t)b * r] = G[keep[a] + (size_t)keep[b] * w] / (d[a] * d[b]);
+        std::vector<double> R1 = S;
+        int info = 0;
+        rails_dpotrf('U', r, R1.data(), r, &info);
+        bool ok = info == 0;
+        for (int a = 0; a < r && ok; ++a)
+            if (!(R1[a + (size_t)a * r] > 1e-6)) ok = false;
+        if (!ok) return absorb_one_by_one(w, coef, keep);
+        for (int b = 0; b < r; ++b)
+            for (int a = b + 1; a < r; ++a) R1[a + (size_t)b * r] = 0.0;
+        // Q1 = X[:, keep] D^-1 R1^-1, written over the whole tail block in place (dropped columns become zero, Q1 fills the
+        // first r tail columns)
+        std::vector<double> M1((size_t)w * w, 0.0), Rinv((size_t)r * r, 0.0);
+        upper_inverse(R1, r, Rinv);
+        for (int b = 0; b < r; ++b)
+            for (int a = 0; a <= b; ++a) M1[keep[a] + (size_t)b * w] = Rinv[a + (size_t)b * r] / d[a];
+        if (!hip_ok(rails_panel_gemm(ctx, 1.0, pp, dim, w, M1.data(), w, w, 0.0, pp, dim), "rails_panel_gemm")) return fail();
+        // second pass: Q = Q1 R2^-1
+        std::vector<double> G2((size_t)r * r), R2;
+        if (!hip_ok(rails_gram(ctx, pp, dim, r, pp, dim, r, G2.data(), r), "rails_gram")) return fail();
+        R2 = G2;
+        rails_dpotrf('U', r, R2.data(), r, &info);
+        if (info != 0) return fail("Cholesky of a nearly orthonormal block failed");
+        for (int b = 0; b < r; ++b)
+            for (int a = b + 1; a < r; ++a) R2[a + (size_t)b * r] = 0.0;
+        std::vector<double> R2inv((size_t)r * r, 0.0);
+        upper_inverse(R2, r, R2inv);
+        if (!hip_ok(rails_panel_gemm(ctx, 1.0, pp, dim, r, R2inv.data(), r, r, 0.0, pp, dim), "rails_panel_gemm")) return fail();
+        // X[:, keep[b]] = Q * (R2 * R1(:, b)) * d[b]
+        for (int b = 0; b < r; ++b)
+            for (int a = 0; a < r; ++a) {
+                double s = 0.0;
+                for (int l = a; l <= b; ++l) s += R2[a + (size_t)l * r] * R1[l + (size_t)b * r];
+                coef[(dim + a) + (size_t)keep[b] * ld] = s * d[b];
+            }
+        dim += r;
+        P.resize(dim);
+        return true;
+    }
+
+    // Re-base P on an orthonormal basis of the column space of all live coefficient matrices.  Exact (to rounding) for every
+    // live multivector; directions no live object uses any more (stale Lanczos start vectors, pre-restart V and AV) go away.
+    void compress()
+    {
+        std::vector<std::shared_ptr<CoefStore>> stores;
+        std::vector<std::weak_ptr<CoefStore>> still;
+        int ncols = 0;
+        for (auto &w : live)
+            if (auto s = w.lock()) {
+                stores.push_back(s);
+                still.push_back(w);
+                ncols += s->ncap;
+            }
+        live.swap(still);
+        if (dim == 0 || ncols == 0) return;
+        std::vector<double> Call((size_t)dim * ncols);
+        int c0 = 0;
+        for (auto &s : stores)
+            for (int j = 0; j < s->ncap; ++j, ++c0) memcpy(Call.data() + (size_t)c0 * dim, s->col(j), sizeof(double) * dim);
+        std::vector<double> Q((size_t)dim * std::min(dim, ncols));
+        int rank = 0, info = 0;
+        rails_range_basis(dim, ncols, Call.data(), dim, 1e-14, Q.data(), dim, &rank, &info);
+        if (info != 0 || rank <= 0 || rank >= dim - 8) return; // nothing (worth it) to drop
+        // device: P2 = P * Q
+        if (P2.N() < 0 || P2.capacity() < rank + 64) {
+            P2 = HipMultiVectorWrapper(m_local, rank + 128, ctx);
+            P2.set_global_rows(m_global);
+        }
+        P2.resize(rank);
+        for (int j0 = 0; j0 < rank; j0 += 256) {
+            int nc = std::min(256, rank - j0);
+            if (!hip_ok(rails_panel_gemm(ctx, 1.0, P.panel(), 0, dim, Q.data() + (size_t)j0 * dim, dim, nc, 0.0, P2.panel(), j0), "rails_panel_gemm")) {
+                failed = true;
+                return;
+            }
+        }
+        // host: C <- Q' C
+        std::vector<double> tmp((size_t)rank);
+        for (auto &s : stores) {
+            std::vector<double> nc((size_t)rank * s->ncap);
+            rails_dgemm('T', 'N', rank, s->ncap, dim, 1.0, Q.data(), dim, s->c.data(), s->ld, 0.0, nc.data(), rank);
+            for (int j = 0; j < s->ncap; ++j) {
+                memcpy(s->col(j), nc.data() + (size_t)j * rank, sizeof(double) * rank);
+                std::fill(s->col(j) + rank, s->col(j) + dim, 0.0);
+            }
+        }
+        std::swap(P, P2);
+        dim = rank;
+        n_compress++;
+    }
+
+private:
+    bool fail(const char *what = nullptr)
+    {
+        if (what) std::cerr << "rails_amd: SubspaceBasis: " << what << std::endl;
+        failed = true;
+        return false;
+    }
+
+    static void upper_inverse(std::vector<double> const &R, int r, std::vector<double> &Rinv)
+    {
+        for (int j = 0; j < r; ++j) {
+            Rinv[j + (size_t)j * r] = 1.0 / R[j + (size_t)j * r];
+            for (int i = j - 1; i >= 0; --i) {
+                double s = 0.0;
+                for (int l = i + 1; l <= j; ++l) s += R[i + (size_t)l * r] * Rinv[l + (size_t)j * r];
+                Rinv[i + (size_t)j * r] = -s / R[i + (size_t)i * r];
+            }
+        }
+    }
+
+    // degenerate block (its kept columns are dependent among themselves after the projection): take the columns one at a
+    // time, each against the basis extended by its predecessors.  The tail block holds the twice-projected columns; coef holds
+    // their coordinates in the old basis.
+    bool absorb_one_by_one(int w, double *coef, std::vector<int> const &keep)
+    {
+        n_single++;
+        const int ld = row_cap;
+        rails_panel *pp = P.panel();
+        const int base = dim;
+        // move the kept columns to the front of the tail one at a time: column j of the block sits at base + j
+        int accepted = 0;
+        for (int idx = 0; idx < (int)keep.size(); ++idx) {
+            const int j = keep[idx];
+            const int src = base + j, dst = base + accepted;
+            if (src != dst && !hip_ok(rails_panel_copy(ctx, pp, src, 1, pp, dst), "rails_panel_copy")) return fail();
+            double g0 = 0.0, g = 0.0;
+            if (!hip_ok(rails_gram(ctx, pp, dst, 1, pp, dst, 1, &g0, 1), "rails_gram")) return fail();
+            for (int round = 0; round < 2 && accepted > 0; ++round) { // against the columns accepted from this block
+                std::vector<double> c(accepted);
+                if (!hip_ok(rails_gram(ctx, pp, base, accepted, pp, dst, 1, c.data(), accepted), "rails_gram")) return fail();
+                if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, base, accepted, c.data(), accepted, 1, 1.0, pp, dst), "rails_panel_gemm")) return fail();
+                for (int a = 0; a < accepted; ++a) coef[(base + a) + (size_t)j * ld] += c[a];
+            }
+            if (!hip_ok(rails_gram(ctx, pp, dst, 1, pp, dst, 1, &g, 1), "rails_gram")) return fail();
+            if (!(g > 1e-24 * g0) || !(g > 0.0)) {
+                n_dropped++;
+                continue;
+            }
+            const double nrm = std::sqrt(g);
+            if (!hip_ok(rails_panel_scale(ctx, pp, dst, 1, 1.0 / nrm), "rails_panel_scale")) return fail();
+            coef[(base + accepted) + (size_t)j * ld] = nrm;
+            accepted++;
+        }
+        dim = base + accepted;
+        P.resize(dim);
+        return true;
+    }
+};
+
+class SubspaceOperator;
+
+// The MultiVector role.  Value semantics as in the reference (src/StlWrapper.cpp:31-121): deep-copy construction, assignment to a
+// non-view shares storage, assignment to a view copies in; views are column windows.
+class SubspaceMultiVector
+{
+    friend class SubspaceOperator;
+    std::shared_ptr<SubspaceBasis> basis_;
+    std::shared_ptr<CoefStore> store_;
+    int c0_ = 0, n_ = -1;
+    int orthogonalized_ = 0;
+    bool is_view_ = false, transpose_ = false;
+
+    int rows() const { return !store_ ? 0 : (store_->in_basis ? basis_->dim : store_->ld); }
+    double *cptr(int j = 0) const { return store_->col(c0_ + j); }
+    int ld() const { return store_->ld; }
+    bool in_basis() const { return !store_ || store_->in_basis; }
+
+    void ensure_cols(int n)
+    {
+        if (!store_) return;
+        if (c0_ + n <= store_->ncap) return;
+        int ncap = c0_ + n;
+        store_->c.resize((size_t)store_->ld * ncap, 0.0);
+        store_->ncap = ncap;
+    }
+
+public:
+    SubspaceMultiVector() {}
+
+    // an in-basis multivector with n columns (capacity n), all zero
+    SubspaceMultiVector(std::shared_ptr<SubspaceBasis> const &b, int n) : basis_(b), store_(b->new_store(std::max(n, 1), true)), n_(n) {}
+
+    // a plain small replicated matrix (rows x n)
+    static SubspaceMultiVector Plain(std::shared_ptr<SubspaceBasis> const &b, int rows, int n)
+    {
+        SubspaceMultiVector out;
+        out.basis_ = b;
+        out.store_ = b->new_store(std::max(n, 1), false, rows);
+        out.n_ = n;
+        return out;
+    }
+
+    SubspaceMultiVector(SubspaceMultiVector const &o) // deep copy (src/StlWrapper.cpp:31-44)
+        : basis_(o.basis_), c0_(0), n_(o.n_), orthogonalized_(o.orthogonalized_), is_view_(false), transpose_(o.transpose_)
+    {
+        if (o.store_) {
+            int cap = std::max(o.store_->ncap - o.c0_, 1);
+            store_ = basis_->new_store(cap, o.store_->in_basis, o.store_->ld);
+            for (int j = 0; j < std::max(o.n_, 0); ++j) memcpy(store_->col(j), o.cptr(j), sizeof(double) * o.rows());
+        }
+    }
+    SubspaceMultiVector(SubspaceMultiVector &&o) = default;
+
+    SubspaceMultiVector(SubspaceMultiVector const &o, int n) // same row space, n columns (src/StlWrapper.cpp:46-51)
+        : basis_(o.basis_), n_(n)
+    {
+        if (o.store_) store_ = basis_->new_store(std::max(n, 1), o.store_->in_basis, o.store_->ld);
+    }
+
+    virtual ~SubspaceMultiVector() {}
+
+    std::shared_ptr<SubspaceBasis> const &basis() const { return basis_; }
+    const double *coefficients() const { return cptr(); }
+    int coefficient_ld() const { return ld(); }
+    int coefficient_rows() const { return rows(); }
+
+    SubspaceMultiVector &operator=(SubspaceMultiVector const &o)
+    {
+        if (!is_view_) { // share
+            basis_ = o.basis_;
+            store_ = o.store_;
+            c0_ = o.c0_;
+            n_ = o.n_;
+            orthogonalized_ = o.orthogonalized_;
+            transpose_ = o.transpose_;
+            return *this;
+        }
+        int cols = std::min(n_, o.n_);
+        for (int j = 0; j < cols; ++j) memcpy(cptr(j), o.cptr(j), sizeof(double) * rows());
+        return *this;
+    }
+
+    SubspaceMultiVector &operator=(double v)
+    {
+        orthogonalized_ = 0;
+        if (!store_ || n_ <= 0) return *this;
+        if (!in_basis() || v == 0.0) {
+            for (int j = 0; j < n_; ++j) std::fill_n(cptr(j), in_basis() ? ld() : rows(), v);
+            return *this;
+        }
+        // every entry of the m-dimensional columns equal to v: one constant vector, expressed in the basis
+        SubspaceBasis &b = *basis_;
+        int t0 = b.tail(1);
+        b.P.resize(t0 + 1);
+        if (!hip_ok(rails_panel_fill(b.ctx, b.P.panel(), t0, 1, v), "rails_panel_fill")) b.failed = true;
+        b.P.resize(t0);
+        std::fill_n(cptr(0), ld(), 0.0);
+        b.absorb_tail(1, cptr(0));
+        for (int j = 1; j < n_; ++j) memcpy(cptr(j), cptr(0), sizeof(double) * ld());
+        return *this;
+    }
+
+    SubspaceMultiVector &operator*=(double s)
+    {
+        for (int j = 0; j < n_; ++j) {
+            double *c = cptr(j);
+            for (int i = 0, r = rows(); i < r; ++i) c[i] *= s;
+        }
+        orthogonalized_ = 0;
+        return *this;
+    }
+    SubspaceMultiVector &operator/=(double s) { return *this *= 1.0 / s; }
+
+    SubspaceMultiVector &axpy(double a, SubspaceMultiVector const &o)
+    {
+        int cols = std::min(n_, o.n_);
+        for (int j = 0; j < cols; ++j) {
+            double *c = cptr(j);
+            const double *x = o.cptr(j);
+            for (int i = 0, r = rows(); i < r; ++i) c[i] += a * x[i];
+        }
+        orthogonalized_ = 0;
+        return *this;
+    }
+    SubspaceMultiVector &operator+=(SubspaceMultiVector const &o) { return axpy(1.0, o); }
+    SubspaceMultiVector &operator-=(SubspaceMultiVector const &o) { return axpy(-1.0, o); }
+    SubspaceMultiVector operator+(SubspaceMultiVector const &o) const
+    {
+        SubspaceMultiVector out(*this);
+        out += o;
+        return out;
+    }
+
+    int M() const { return transpose_ ? n_ : (in_basis() ? (basis_ ? (int)basis_->m_global : -1) : store_->ld); }
+    int N() const { return transpose_ ? (in_basis() ? (basis_ ? (int)basis_->m_global : -1) : store_->ld) : n_; }
+
+    void resize(int n) // capacity preserving (src/StlWrapper.cpp:219-263)
+    {
+        orthogonalized_ = std::min(orthogonalized_, n);
+        ensure_cols(n);
+        n_ = n;
+    }
+
+    // zero the allocated columns past the ones in use: they hold pre-restart vectors that nothing reads again, and would keep
+    // their directions alive in SubspaceBasis::compress()
+    void discard_unused_columns()
+    {
+        if (!store_ || is_view_) return;
+        for (int j = c0_ + std::max(n_, 0); j < store_->ncap; ++j) std::fill_n(store_->col(j), store_->ld, 0.0);
+    }
+
+    SubspaceMultiVector view(int a = -1, int b = -1) const
+    {
+        SubspaceMultiVector out;
+        out.basis_ = basis_;
+        out.store_ = store_;
+        out.transpose_ = transpose_;
+        out.is_view_ = true;
+        int num = 1;
+        if (b > 0 && a >= 0)
+            num = b - a + 1;
+        else if (a < 0) {
+            a = 0;
+            num = n_;
+        }
+        out.c0_ = c0_ + a;
+        out.n_ = num;
+        return out;
+    }
+
+    SubspaceMultiVector copy() const { return SubspaceMultiVector(*this); }
+
+    void push_back(SubspaceMultiVector const &o) // src/StlWrapper.cpp:367-374
+    {
+        if (!store_) { // empty default-constructed target takes the shape of the source
+            basis_ = o.basis_;
+            store_ = basis_->new_store(std::max(o.n_, 1), o.store_->in_basis, o.store_->ld);
+            n_ = 0;
+        }
+        int n = n_, on = o.n_;
+        resize(n + on);
+        for (int j = 0; j < on; ++j) memcpy(cptr(n + j), o.cptr(j), sizeof(double) * rows());
+    }
+
+    // U(-1,1) entries in the m-dimensional space (src/StlWrapper.cpp:414-423): drawn on the device into the basis panel's tail
+    // (one RNG stream per call, like the direct back end), then expressed in the basis
+    void random()
+    {
+        if (!in_basis() || n_ <= 0) {
+            if (!in_basis()) std::cerr << "rails_amd: random() on a plain replicated object is not supported" << std::endl;
+            return;
+        }
+        SubspaceBasis &b = *basis_;
+        for (int j0 = 0; j0 < n_; j0 += 64) {
+            int w = std::min(64, n_ - j0);
+            int t0 = b.tail(w);
+            b.P.resize(t0 + w);
+            if (!hip_ok(rails_panel_random(b.ctx, b.P.panel(), t0, w), "rails_panel_random")) b.failed = true;
+            b.P.resize(t0);
+            for (int j = 0; j < w; ++j) std::fill_n(cptr(j0 + j), ld(), 0.0);
+            b.absorb_tail(w, cptr(j0));
+        }
+        orthogonalized_ = 0;
+    }
+
+    SubspaceMultiVector transpose() const
+    {
+        SubspaceMultiVector out = view();
+        out.is_view_ = false;
+        out.transpose_ = !transpose_;
+        out.orthogonalized_ = orthogonalized_;
+        return out;
+    }
+
+    // X' Y (src/StlWrapper.cpp:394-412): P is orthonormal, so the m-dimensional inner products are coefficient inner products
+    HostDenseMatrix dot(SubspaceMultiVector const &o) const
+    {
+        HostDenseMatrix out(n_, o.n_);
+        if (in_basis() != o.in_basis() || rows() != o.rows()) {
+            std::cerr << "Incomplatible matrices of sizes " << M() << "x" << N() << " and " << o.M() << "x" << o.N() << std::endl;
+            return out;
+        }
+        if (n_ > 0 && o.n_ > 0 && rows() > 0) rails_dgemm('T', 'N', n_, o.n_, rows(), 1.0, cptr(), ld(), o.cptr(), o.ld(), 0.0, (double *)out, out.LDA());
+        return out;
+    }
+
+    SubspaceMultiVector operator*(HostDenseMatrix const &C) const // src/StlWrapper.cpp:168-187
+    {
+        SubspaceMultiVector out(*this, C.N());
+        if (C.M() != n_) {
+            std::cerr << "Incomplatible matrices of sizes " << M() << "x" << N() << " and " << C.M() << "x" << C.N() << std::endl;
+            return out;
+        }
+        if (C.N() > 0 && n_ > 0 && rows() > 0)
+            rails_dgemm('N', C.transposed() ? 'T' : 'N', rows(), C.N(), n_, 1.0, cptr(), ld(), (double *)C, C.raw_ld(), 0.0, out.cptr(), out.ld());
+        return out;
+    }
+
+    // op(this) * other (src/MatrixOrMultiVectorWrapper.hpp:54,59): B'W -> plain p x w; B y with y plain -> in-basis
+    SubspaceMultiVector operator*(SubspaceMultiVector const &o) const
+    {
+        if (transpose_) {
+            SubspaceMultiVector out = Plain(basis_, n_, o.n_);
+            if (rows() != o.rows() || in_basis() != o.in_basis()) {
+                std::cerr << "Incomplatible matrices of sizes " << M() << "x" << N() << " and " << o.M() << "x" << o.N() << std::endl;
+                return out;
+            }
+            if (n_ > 0 && o.n_ > 0 && rows() > 0) rails_dgemm('T', 'N', n_, o.n_, rows(), 1.0, cptr(), ld(), o.cptr(), o.ld(), 0.0, out.cptr(), out.ld());
+            return out;
+        }
+        SubspaceMultiVector out(*this, o.n_);
+        if (o.in_basis() || o.rows() != n_) {
+            std::cerr << "Incomplatible matrices of sizes " << M() << "x" << N() << " and " << o.M() << "x" << o.N() << std::endl;
+            return out;
+        }
+        if (o.n_ > 0 && n_ > 0 && rows() > 0) rails_dgemm('N', 'N', rows(), o.n_, n_, 1.0, cptr(), ld(), o.cptr(), o.ld(), 0.0, out.cptr(), out.ld());
+        return out;
+    }
+
+    double norm() const // spectral 2-norm (src/StlWrapper.cpp:265-289)
+    {
+        if (n_ <= 0) return 0.0;
+        HostDenseMatrix G = dot(*this);
+        std::vector<double> w(n_);
+        int info = 0;
+        rails_dsyev('V', 'U', n_, (double *)G, G.LDA(), w.data(), &info);
+        double mx = 0.0;
+        for (int i = 0; i < n_; ++i) mx = std::max(mx, std::sqrt(std::abs(w[i])));
+        return mx;
+    }
+
+    // the reference's recurrence (src/StlWrapper.cpp:305-321) on the coefficient columns
+    void orthogonalize()
+    {
+        const int r = rows();
+        std::vector<double> h;
+        for (int i = orthogonalized_; i < n_; ++i) {
+            double *v = cptr(i);
+            auto nrm2 = [&]() {
+                double s = 0.0;
+                for (int l = 0; l < r; ++l) s += v[l] * v[l];
+                return std::sqrt(s);
+            };
+            double nr = nrm2();
+            for (int l = 0; l < r; ++l) v[l] /= nr;
+            for (int pass = 0; pass < 2 && i > 0; ++pass) {
+                h.assign(i, 0.0);
+                rails_dgemm('T', 'N', i, 1, r, 1.0, cptr(), ld(), v, ld(), 0.0, h.data(), i);
+                rails_dgemm('N', 'N', r, 1, i, -1.0, cptr(), ld(), h.data(), i, 1.0, v, ld());
+            }
+            nr = nrm2();
+            for (int l = 0; l < r; ++l) v[l] /= nr;
+        }
+        orthogonalized_ = n_;
+    }
+
+    // device image P * C (m_local x n): used by the operator, the final read-out and the tests
+    HipMultiVectorWrapper materialise() const { return basis_->materialise(cptr(), ld(), n_); }
+    void to_host(double *data, int64_t ldd) const
+    {
+        if (!in_basis()) {
+            for (int j = 0; j < n_; ++j) memcpy(data + (size_t)j * ldd, cptr(j), sizeof(double) * rows());
+            return;
+        }
+        materialise().to_host(data, ldd);
+    }
+
+    // set the columns from m_local x n host data (tests, I/O): upload, express in the basis
+    void from_host(const double *data, int64_t ldd)
+    {
+        orthogonalized_ = 0;
+        if (!store_ || n_ <= 0) return;
+        if (!in_basis()) {
+            for (int j = 0; j < n_; ++j) memcpy(cptr(j), data + (size_t)j * ldd, sizeof(double) * rows());
+            return;
+        }
+        HipMultiVectorWrapper X(basis_->m_local, n_, basis_->ctx);
+        X.from_host(data, ldd);
+        SubspaceMultiVector tmp = Absorb(basis_, X);
+        for (int j = 0; j < n_; ++j) memcpy(cptr(j), tmp.cptr(j), sizeof(double) * ld());
+    }
+    int64_t local_rows() const { return in_basis() ? basis_->m_local : rows(); }
+    int orthogonalized() const { return orthogonalized_; }
+    void set_orthogonalized(int n) { orthogonalized_ = n; }
+    int capacity() const { return store_ ? store_->ncap - c0_ : 0; }
+    bool replicated() const { return !in_basis(); }
+    const double *host_data() const { return cptr(); }
+
+    // express a device multivector (m_local x n) in the basis, extending it as needed
+    static SubspaceMultiVector Absorb(std::shared_ptr<SubspaceBasis> const &b, HipMultiVectorWrapper const &X)
+    {
+        const int n = X.N();
+        SubspaceMultiVector out(b, n);
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            int w = std::min(64, n - j0);
+            int t0 = b->tail(w);
+            b->P.resize(t0 + w);
+            if (!hip_ok(rails_panel_copy(b->ctx, X.panel(), X.offset() + j0, w, b->P.panel(), t0), "rails_panel_copy")) b->failed = true;
+            b->P.resize(t0);
+            b->absorb_tail(w, out.cptr(j0));
+        }
+        return out;
+    }
+};
+
+inline SubspaceMultiVector operator*(double d, SubspaceMultiVector const &o)
+{
+    SubspaceMultiVector out(o);
+    out *= d;
+    return out;
+}
+
+// The Matrix role: A * W = materialise W, CSR SpMM straight into the basis panel's tail, absorb
+class SubspaceOperator
+{
+    HipOperatorWrapper A_;
+    std::shared_ptr<SubspaceBasis> basis_;
+
+public:
+    SubspaceOperator() {}
+    SubspaceOperator(HipOperatorWrapper const &A, std::shared_ptr<SubspaceBasis> const &b) : A_(A), basis_(b) {}
+    virtual ~SubspaceOperator() {}
+
+    int M() const { return A_.M(); }
+    int N() const { return A_.N(); }
+    SubspaceOperator transpose() const { return SubspaceOperator(A_.transpose(), basis_); }
+    double norm() const { return A_.norm(); }
+
+    SubspaceMultiVector operator*(SubspaceMultiVector const &X) const
+    {
+        SubspaceBasis &b = *basis_;
+        const int n = X.N();
+        SubspaceMultiVector out(basis_, n);
+        if (n <= 0) return out;
+        HipMultiVectorWrapper Xd = X.materialise();
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            int w = std::min(64, n - j0);
+            int t0 = b.tail(w);
+            b.P.resize(t0 + w);
+            HipMultiVectorWrapper Xw = Xd.view(j0, j0 + w - 1);
+            if (w == 1) Xw = Xd.view(j0);
+            if (!A_.apply_into(Xw, b.P, t0)) b.failed = true;
+            b.P.resize(t0);
+            b.absorb_tail(w, out.cptr(j0));
+        }
+        return out;
+    }
+};
+
+// the restart products are coefficient GEMMs; afterwards the basis is re-based on what is still alive
+template <>
+struct SolverOps<SubspaceOperator, SubspaceMultiVector, HostDenseMatrix> {
+    typedef Solver<SubspaceOperator, SubspaceMultiVector, HostDenseMatrix> SolverT;
+    struct State {
+    };
+    struct Lanczos {
+        HostDenseMatrix eigenvalues;
+        SubspaceMultiVector eigenvectors;
+        void append_to(SubspaceMultiVector &V, std::vector<int> const &indices, int count) const
+        {
+            for (int i = 0; i < count; i++) V.push_back(eigenvectors.view(indices[i]));
+        }
+    };
+    static SubspaceMultiVector apply_append(SubspaceOperator const &A, SubspaceMultiVector const &W, SubspaceMultiVector &AV)
+    {
+        SubspaceMultiVector AW = A * W;
+        AV.push_back(AW);
+        return AW;
+    }
+    static int lanczos(SolverT &solver, State &, SubspaceMultiVector const &AV, SubspaceMultiVector const &MV, HostDenseMatrix const &T,
+                       HostDenseMatrix const &, SubspaceMultiVector const &, int max_iter, Lanczos &out)
+    {
+        HostDenseMatrix H(max_iter + 1, max_iter + 1);
+        out.eigenvalues = HostDenseMatrix(max_iter, 1);
+        return solver.resid_lanczos(AV, MV, T, H, out.eigenvectors, out.eigenvalues, max_iter);
+    }
+    static void multiply_inplace(SubspaceMultiVector &V, HostDenseMatrix const &X)
+    {
+        V.view(0, X.N() - 1) = V * X;
+        V.resize(X.N());
+        V.discard_unused_columns();
+    }
+    static void on_restart(State &, HostDenseMatrix const &, SubspaceMultiVector &V, SubspaceMultiVector &)
+    {
+        if (V.basis()) V.basis()->compress();
+    }
+};
+
+typedef Solver<SubspaceOperator, SubspaceMultiVector, HostDenseMatrix> SubspaceSolver;
+
+} // namespace rails
+
+#endif

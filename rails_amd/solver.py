@@ -96,6 +96,12 @@ class Solver:
         check(self.lib.rails_solver_relative_residual(self.h, C.byref(rel)), "rails_solver_relative_residual")
         return rel.value
 
+    def backend_stats(self):
+        """counters of the coordinate-space back end for the last solve ({} when the direct back end ran)"""
+        import json
+
+        return json.loads(self.lib.rails_solver_backend_stats(self.h).decode())
+
     def close(self):
         if self.h:
             if self.ctx.h:  # after the context is gone the handle cannot be released safely any more

@@ -15,10 +15,13 @@ def run(ctx, A, B, params, seed, proj):
     s = rails_amd.Solver(ctx, op, B)
     assert s.set_parameters(params) == 0
     s.set_option("verbose", 0)
-    s.set_option("projected_lanczos", proj)
+    s.set_option("projected_lanczos", 1 if proj == 1 else 0)
+    s.set_option("subspace", 1 if proj == 2 else 0)
     b = ctx.stats()
     code, V, T = s.solve()
     a = ctx.stats()
+    if proj == 2:
+        print("   backend:", s.backend_stats(), "orth %.1e" % np.abs(V.T @ V - np.eye(V.shape[1])).max(), "rel %.2e" % s.relative_residual())
     return code, s.history(), s.trips(), a["lanczos_start"] - b["lanczos_start"], V @ T @ V.T
 
 def main():
@@ -36,7 +39,7 @@ def main():
         out = orc.solve(A, B, orc.params({**prm, "rng_mode": 1, "seed": seed}))
         ho = np.array(out["res_hist"])
         Xo = out["V"] @ out["T"] @ out["V"].T
-        for proj in (0, 1):
+        for proj in (0, 1, 2):
             code, h, trips, nstart, X = run(ctx, A, B, prm, seed, proj)
             h = np.array(h)
             n = min(len(h), len(ho))

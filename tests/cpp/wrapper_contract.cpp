@@ -1,6 +1,7 @@
-// Contract test of the three classes that plug into Solver<Matrix, MultiVector, DenseMatrix> (the drop-in boundary,
-// SURVEY.md 8(b)): rails::HipOperatorWrapper, rails::HipMultiVectorWrapper, rails::HostDenseMatrix.  The cases restate, for these
-// classes, what the reference's typed tests demand of every back end:
+// Contract test of the classes that plug into Solver<Matrix, MultiVector, DenseMatrix> (the drop-in boundary):
+// rails::HipOperatorWrapper, rails::HipMultiVectorWrapper, rails::HostDenseMatrix, and the coordinate-space back end
+// rails::SubspaceOperator / rails::SubspaceMultiVector (same multivector cases, instantiated from one template).  The cases
+// restate, for these classes, what the reference's typed tests demand of every back end:
 //   test/GenericMultiVectorWrapper_test.cpp:63-507, test/GenericOperatorWrapper_test.cpp:74-114,187-229,
 //   test/GenericDenseMatrixWrapper_test.cpp:61-209
 // (the reference gets element access from a `Testable...` subclass, test/Epetra_TestableWrappers.hpp:14-95; here element
@@ -18,10 +19,33 @@
 #include <vector>
 
 #include "rails/HipSolverOps.hpp"
+#include "rails/SubspaceWrappers.hpp"
 
 using rails::HipMultiVectorWrapper;
 using rails::HipOperatorWrapper;
 using rails::HostDenseMatrix;
+using rails::SubspaceBasis;
+using rails::SubspaceMultiVector;
+using rails::SubspaceOperator;
+
+// the two device back ends behind one test body: how to make a 10 x n multivector, a small replicated one, and how exact the
+// element-wise comparisons can be (coordinates in a basis reproduce entries to rounding, not bit for bit)
+struct HipTraits {
+    typedef HipMultiVectorWrapper MV;
+    rails_ctx *ctx;
+    double tol;
+    const char *name;
+    MV make(int n) const { return MV(10, n, ctx); }
+    MV small(int rows, int n) const { return MV::Replicated(rows, n, ctx); }
+};
+struct SubspaceTraits {
+    typedef SubspaceMultiVector MV;
+    std::shared_ptr<SubspaceBasis> basis;
+    double tol;
+    const char *name;
+    MV make(int n) const { return MV(basis, n); }
+    MV small(int rows, int n) const { return MV::Plain(basis, rows, n); }
+};
 
 static int g_fail = 0, g_checks = 0;
 static const char *g_case = "";
@@ -45,26 +69,33 @@ static const char *g_case = "";
     } while (0)
 
 // ---- element access for the device multivector --------------------------------------------------------------------------
-static std::vector<double> host_of(HipMultiVectorWrapper const &v) // column-major M x N
+template <class MV>
+static std::vector<double> host_of(MV const &v) // column-major M x N
 {
     int m = (int)v.local_rows(), n = v.N();
     std::vector<double> h((size_t)m * std::max(n, 0));
     if (n > 0) v.to_host(h.data(), m);
     return h;
 }
-static double get(HipMultiVectorWrapper const &v, int i, int j) { return host_of(v)[i + (size_t)j * v.local_rows()]; }
-static void set(HipMultiVectorWrapper &v, int i, int j, double x)
+template <class MV>
+static double get(MV const &v, int i, int j)
+{
+    return host_of(v)[i + (size_t)j * v.local_rows()];
+}
+template <class MV>
+static void set(MV &v, int i, int j, double x)
 {
     int m = (int)v.local_rows();
     std::vector<double> col(m);
-    HipMultiVectorWrapper c = v.view(j);
+    MV c = v.view(j);
     c.to_host(col.data(), m);
     col[i] = x;
     int w = v.orthogonalized();
     c.from_host(col.data(), m);
     v.set_orthogonalized(std::min(w, j)); // writing into column j invalidates the watermark from there on
 }
-static bool same(HipMultiVectorWrapper const &a, HipMultiVectorWrapper const &b, double tol = 0.0)
+template <class MV>
+static bool same(MV const &a, MV const &b, double tol = 0.0)
 {
     if (a.M() != b.M() || a.N() != b.N()) return false;
     std::vector<double> ha = host_of(a), hb = host_of(b);
@@ -72,7 +103,8 @@ static bool same(HipMultiVectorWrapper const &a, HipMultiVectorWrapper const &b,
         if (!(std::abs(ha[i] - hb[i]) <= tol)) return false;
     return true;
 }
-static bool orthonormal(HipMultiVectorWrapper const &a)
+template <class MV>
+static bool orthonormal(MV const &a)
 {
     HostDenseMatrix G = a.dot(a);
     for (int i = 0; i < G.M(); ++i)
@@ -81,9 +113,10 @@ static bool orthonormal(HipMultiVectorWrapper const &a)
     return true;
 }
 
+template <class TR>
 struct MVFixture { // four 10 x 10 multivectors, one column in use (GenericMultiVectorWrapper_test.cpp:14-48)
-    HipMultiVectorWrapper a, b, c, d;
-    explicit MVFixture(rails_ctx *ctx) : a(10, 10, ctx), b(10, 10, ctx), c(10, 10, ctx), d(10, 10, ctx) { resize(1); }
+    typename TR::MV a, b, c, d;
+    explicit MVFixture(TR const &tr) : a(tr.make(10)), b(tr.make(10)), c(tr.make(10)), d(tr.make(10)) { resize(1); }
     void resize(int n)
     {
         a.resize(n);
@@ -93,14 +126,21 @@ struct MVFixture { // four 10 x 10 multivectors, one column in use (GenericMulti
     }
 };
 
-static void multivector_cases(rails_ctx *ctx)
+template <class TR>
+static void multivector_cases(TR const &tr)
 {
-    auto run = [&](const char *name, std::function<void(MVFixture &)> body) {
-        g_case = name;
-        MVFixture f(ctx);
+    typedef typename TR::MV MV;
+    typedef MVFixture<TR> Fx;
+    const double tol = tr.tol; // 0 for the direct back end
+    auto run = [&](const char *name, std::function<void(Fx &)> body) {
+        static std::string label;
+        label = std::string(tr.name) + "." + name;
+        g_case = label.c_str();
+        if (getenv("RAILS_CONTRACT_VERBOSE")) std::printf("case %s\n", g_case);
+        Fx f(tr);
         body(f);
     };
-    run("MV.Resize", [](MVFixture &f) {
+    run("MV.Resize", [&](Fx &f) {
         f.a.resize(0);
         CHECK(f.a.N() == 0);
         f.a.resize(0);
@@ -110,68 +150,68 @@ static void multivector_cases(rails_ctx *ctx)
         f.a.resize(1);
         CHECK(f.a.N() == 1);
     });
-    run("MV.PutScalar", [](MVFixture &f) {
+    run("MV.PutScalar", [&](Fx &f) {
         f.a = 2.0;
-        for (int i = 0; i < 10; ++i) CHECK(get(f.a, i, 0) == 2.0);
+        for (int i = 0; i < 10; ++i) CHECK_NEAR(get(f.a, i, 0), 2.0, tol);
     });
-    run("MV.Assignment shares storage", [](MVFixture &f) {
+    run("MV.Assignment shares storage", [&](Fx &f) {
         f.a.random();
         f.b = f.a;
         f.b = 2.0;
-        CHECK(same(f.b, f.a));
-        CHECK(get(f.a, 3, 0) == 2.0);
+        CHECK(same(f.b, f.a, tol));
+        CHECK_NEAR(get(f.a, 3, 0), 2.0, tol);
     });
-    run("MV.ScaleAssign", [](MVFixture &f) {
+    run("MV.ScaleAssign", [&](Fx &f) {
         f.a.random();
         f.b = f.a.copy();
         f.b *= 2.5;
-        for (int i = 0; i < 10; ++i) CHECK(get(f.b, i, 0) == get(f.a, i, 0) * 2.5);
+        for (int i = 0; i < 10; ++i) CHECK_NEAR(get(f.b, i, 0), get(f.a, i, 0) * 2.5, tol);
     });
-    run("MV.AddAssign", [](MVFixture &f) {
+    run("MV.AddAssign", [&](Fx &f) {
         f.a.random();
         f.b = f.a.copy();
         f.b += f.a;
         f.a *= 2.0;
-        CHECK(same(f.a, f.b));
+        CHECK(same(f.a, f.b, tol));
     });
-    run("MV.SubAssign", [](MVFixture &f) {
+    run("MV.SubAssign", [&](Fx &f) {
         f.a.random();
         f.b = f.a.copy();
         f.b -= f.a;
         f.a = 0.0;
-        CHECK(same(f.a, f.b));
+        CHECK(same(f.a, f.b, tol));
     });
-    run("MV.DivAssign", [](MVFixture &f) {
+    run("MV.DivAssign", [&](Fx &f) {
         f.a.random();
         f.b = f.a.copy();
         f.b *= 1.0 / 13.0;
         f.a /= 13;
-        CHECK(same(f.a, f.b));
+        CHECK(same(f.a, f.b, tol));
     });
-    run("MV.Addition", [](MVFixture &f) {
+    run("MV.Addition", [&](Fx &f) {
         f.a.random();
         f.b = f.a.copy();
         f.b *= 2.0;
         f.d = f.a + f.b;
-        for (int i = 0; i < 10; ++i) CHECK(get(f.d, i, 0) == get(f.a, i, 0) + get(f.b, i, 0));
+        for (int i = 0; i < 10; ++i) CHECK_NEAR(get(f.d, i, 0), get(f.a, i, 0) + get(f.b, i, 0), tol);
         CHECK(!same(f.d, f.a)); // a + b is a new object
     });
-    run("MV.ScalarTimes", [](MVFixture &f) {
+    run("MV.ScalarTimes", [&](Fx &f) {
         f.a.random();
         f.b = f.a.copy();
         f.b *= 13.0;
         f.c = 13 * f.a;
-        CHECK(same(f.b, f.c));
+        CHECK(same(f.b, f.c, tol));
     });
-    run("MV.Norm", [](MVFixture &f) {
+    run("MV.Norm", [&](Fx &f) {
         f.a.random();
         double s = 0.0;
         for (int i = 0; i < 10; ++i) s += get(f.a, i, 0) * get(f.a, i, 0);
-        CHECK_NEAR(std::sqrt(s), f.a.norm(), 4e-16 * std::sqrt(s));
+        CHECK_NEAR(std::sqrt(s), f.a.norm(), 4e-16 * std::sqrt(s) + tol);
         f.a /= f.a.norm();
-        CHECK_NEAR(1.0, f.a.norm(), 4e-16);
+        CHECK_NEAR(1.0, f.a.norm(), 4e-16 + tol);
     });
-    run("MV.NormView", [](MVFixture &f) {
+    run("MV.NormView", [&](Fx &f) {
         f.resize(2);
         f.a.random();
         double n1 = 0.0, n2 = 0.0;
@@ -182,21 +222,21 @@ static void multivector_cases(rails_ctx *ctx)
         n1 = std::sqrt(n1);
         n2 = std::sqrt(n2);
         CHECK(n1 != 0.0 && n2 != 0.0 && n1 != n2);
-        CHECK_NEAR(n1, f.a.view(0).norm(), 4e-16 * n1);
-        CHECK_NEAR(n2, f.a.view(1).norm(), 4e-16 * n2);
+        CHECK_NEAR(n1, f.a.view(0).norm(), 4e-16 * n1 + tol);
+        CHECK_NEAR(n2, f.a.view(1).norm(), 4e-16 * n2 + tol);
         CHECK(f.a.N() == 2);
         CHECK(f.a.norm() != n1 && f.a.norm() != n2); // 2-norm of the pair, not of a column
     });
-    run("MV.Dot", [](MVFixture &f) {
+    run("MV.Dot", [&](Fx &f) {
         f.a.random();
         f.b.random();
         double s = 0.0;
         for (int i = 0; i < 10; ++i) s += get(f.a, i, 0) * get(f.b, i, 0);
         HostDenseMatrix c = f.a.dot(f.b);
         CHECK(c.M() == 1 && c.N() == 1);
-        CHECK_NEAR(s, c(0, 0), 1e-15);
+        CHECK_NEAR(s, c(0, 0), 1e-15 + tol);
     });
-    run("MV.Dot unequal widths", [](MVFixture &f) {
+    run("MV.Dot unequal widths", [&](Fx &f) {
         f.a.resize(2);
         f.a.random();
         f.b.resize(3);
@@ -207,10 +247,10 @@ static void multivector_cases(rails_ctx *ctx)
             for (int j = 0; j < 2; ++j) {
                 double s = 0.0;
                 for (int i = 0; i < 10; ++i) s += get(f.a, i, j) * get(f.b, i, k);
-                CHECK_NEAR(s, c(j, k), 1e-15);
+                CHECK_NEAR(s, c(j, k), 1e-15 + tol);
             }
     });
-    run("MV.Orthogonalize known answer", [](MVFixture &f) {
+    run("MV.Orthogonalize known answer", [&](Fx &f) {
         f.resize(2);
         f.a = 0.0;
         set(f.a, 0, 0, 2.3);
@@ -220,15 +260,15 @@ static void multivector_cases(rails_ctx *ctx)
         f.b = 0.0;
         set(f.b, 0, 0, 1.0);
         set(f.b, 1, 1, 1.0);
-        CHECK(same(f.b, f.a, 4e-16));
+        CHECK(same(f.b, f.a, 4e-16 + tol));
     });
-    run("MV.Orthogonalize push_back watermark", [](MVFixture &f) {
+    run("MV.Orthogonalize push_back watermark", [&](Fx &f) {
         f.a = 0.0;
         set(f.a, 0, 0, 2.3);
         f.b = 0.0;
         set(f.b, 0, 0, 1.0);
         f.a.orthogonalize();
-        CHECK(same(f.b, f.a, 4e-16));
+        CHECK(same(f.b, f.a, 4e-16 + tol));
         f.b.resize(2);
         f.b = 0.0;
         set(f.b, 0, 0, 1.0);
@@ -238,9 +278,9 @@ static void multivector_cases(rails_ctx *ctx)
         set(f.c, 1, 0, 2.7);
         f.a.push_back(f.c);
         f.a.orthogonalize();
-        CHECK(same(f.b, f.a, 4e-16));
+        CHECK(same(f.b, f.a, 4e-16 + tol));
     });
-    run("MV.Orthogonalize random", [](MVFixture &f) {
+    run("MV.Orthogonalize random", [&](Fx &f) {
         f.a.resize(3);
         f.a.random();
         f.a.orthogonalize();
@@ -252,7 +292,7 @@ static void multivector_cases(rails_ctx *ctx)
         CHECK(orthonormal(f.a));
         CHECK(f.a.N() == 6);
     });
-    run("MV.Orthogonalize after modification", [](MVFixture &f) {
+    run("MV.Orthogonalize after modification", [&](Fx &f) {
         f.a.resize(3);
         f.a.random();
         f.a.orthogonalize();
@@ -275,7 +315,7 @@ static void multivector_cases(rails_ctx *ctx)
         f.a.orthogonalize();
         CHECK(orthonormal(f.a));
     });
-    run("MV.Resize after sharing", [](MVFixture &f) {
+    run("MV.Resize after sharing", [&](Fx &f) {
         f.a.resize(20);
         CHECK(f.a.N() == 20);
         f.a.random();
@@ -285,66 +325,66 @@ static void multivector_cases(rails_ctx *ctx)
         f.b.random();
         f.a = f.b;
         CHECK(f.a.N() == 10);
-        CHECK(same(f.b, f.a));
+        CHECK(same(f.b, f.a, tol));
         f.a.resize(10);
         CHECK(f.a.N() == 10);
-        CHECK(same(f.b, f.a));
+        CHECK(same(f.b, f.a, tol));
     });
-    run("MV.Resize keeps data inside the capacity", [](MVFixture &f) {
+    run("MV.Resize keeps data inside the capacity", [&](Fx &f) {
         f.a.resize(1);
         f.a.random();
         f.b = f.a.copy();
         f.a.resize(10);
         f.c = f.a.view(0);
-        CHECK(same(f.b, f.c));
+        CHECK(same(f.b, f.c, tol));
     });
-    run("MV.View assigns through", [](MVFixture &f) {
+    run("MV.View assigns through", [&](Fx &f) {
         f.a.random();
         f.b = f.a.copy();
         f.b.random();
         f.a.view(0) = f.b;
-        CHECK(same(f.b, f.a));
+        CHECK(same(f.b, f.a, tol));
     });
-    run("MV.View of a shared object", [](MVFixture &f) {
+    run("MV.View of a shared object", [&](Fx &f) {
         f.a.random();
         f.b = f.a;
-        CHECK(same(f.b, f.a));
+        CHECK(same(f.b, f.a, tol));
         f.c.random();
         f.b = f.c;
-        CHECK(same(f.b, f.c));
+        CHECK(same(f.b, f.c, tol));
         CHECK(get(f.a, 0, 0) != get(f.b, 0, 0));
         f.b = f.a;
         f.b.view() = f.c;
-        CHECK(same(f.a, f.c));
-        CHECK(same(f.b, f.c));
+        CHECK(same(f.a, f.c, tol));
+        CHECK(same(f.b, f.c, tol));
     });
-    run("MV.Copy is deep", [](MVFixture &f) {
+    run("MV.Copy is deep", [&](Fx &f) {
         f.a.random();
         f.b = f.a;
         f.b.random();
-        CHECK(same(f.b, f.a));
+        CHECK(same(f.b, f.a, tol));
         f.b = f.a.copy();
-        CHECK(same(f.b, f.a));
+        CHECK(same(f.b, f.a, tol));
         f.b.random();
         CHECK(get(f.a, 0, 0) != get(f.b, 0, 0));
-        HipMultiVectorWrapper other = f.a.copy();
-        CHECK(same(f.a, other));
+        MV other = f.a.copy();
+        CHECK(same(f.a, other, tol));
         other.random();
         CHECK(get(f.a, 0, 0) != get(other, 0, 0));
     });
-    run("MV.PushBack", [](MVFixture &f) {
+    run("MV.PushBack", [&](Fx &f) {
         f.a.resize(3);
         f.a.random();
         f.b = f.a.view(0).copy();
         f.b.push_back(f.a.view(1));
         f.b.push_back(f.a.view(2));
-        CHECK(same(f.b, f.a));
+        CHECK(same(f.b, f.a, tol));
         f.a.random();
         f.b = f.a.view(0).copy();
         f.b.push_back(f.a.view(1, 2));
-        CHECK(same(f.b, f.a));
+        CHECK(same(f.b, f.a, tol));
     });
-    run("MV.Transpose products", [ctx](MVFixture &f) {
+    run("MV.Transpose products", [&](Fx &f) {
         // (10 x 10)' * (10 x 1) is the B'W shape of the solver: a small replicated result; (10 x 10) * y is the B*y shape
         // with y a replicated 10 x 1 object (src/MatrixOrMultiVectorWrapper.hpp:54,59)
         f.a.resize(10);
@@ -356,30 +396,30 @@ static void multivector_cases(rails_ctx *ctx)
         f.b.resize(1);
         f.b.random();
         double b0 = get(f.b, 0, 0), b1 = get(f.b, 1, 0);
-        HipMultiVectorWrapper c = f.a.transpose() * f.b;
+        MV c = f.a.transpose() * f.b;
         CHECK(c.replicated() && c.M() == 10 && c.N() == 1);
-        CHECK_NEAR(b0 + 3.0 * b1, c.host_data()[0], 1e-14);
-        CHECK_NEAR(2.0 * b0 + 4.0 * b1, c.host_data()[1], 1e-14);
-        HipMultiVectorWrapper y = HipMultiVectorWrapper::Replicated(10, 1, ctx);
+        CHECK_NEAR(b0 + 3.0 * b1, c.host_data()[0], 1e-14 + tol);
+        CHECK_NEAR(2.0 * b0 + 4.0 * b1, c.host_data()[1], 1e-14 + tol);
+        MV y = tr.small(10, 1);
         std::vector<double> hb = host_of(f.b);
         y.from_host(hb.data(), 10);
-        HipMultiVectorWrapper d = f.a * y;
+        MV d = f.a * y;
         CHECK(!d.replicated() && d.M() == 10 && d.N() == 1);
-        CHECK_NEAR(b0 + 2.0 * b1, get(d, 0, 0), 1e-14);
-        CHECK_NEAR(3.0 * b0 + 4.0 * b1, get(d, 1, 0), 1e-14);
+        CHECK_NEAR(b0 + 2.0 * b1, get(d, 0, 0), 1e-14 + tol);
+        CHECK_NEAR(3.0 * b0 + 4.0 * b1, get(d, 1, 0), 1e-14 + tol);
     });
-    run("MV.Transpose shapes", [](MVFixture &f) {
+    run("MV.Transpose shapes", [&](Fx &f) {
         f.a.resize(1);
         CHECK(f.a.M() == 10 && f.a.N() == 1);
         CHECK(f.a.transpose().M() == 1 && f.a.transpose().N() == 10);
     });
-    run("MV.Construct like another", [](MVFixture &f) { // (other, n): same rows, n columns (src/StlWrapper.cpp:46-51; uses :125,156,372)
+    run("MV.Construct like another", [&](Fx &f) { // (other, n): same rows, n columns (src/StlWrapper.cpp:46-51; uses :125,156,372)
         f.a.resize(3);
-        HipMultiVectorWrapper q(f.a, 7);
+        MV q(f.a, 7);
         CHECK(q.M() == 10 && q.N() == 7 && q.capacity() >= 7);
-        HipMultiVectorWrapper e;
+        MV e;
         e.push_back(f.a.view(1)); // default-constructed target (src/LyapunovSolver.hpp:129)
-        CHECK(e.N() == 1 && same(e, f.a.view(1)));
+        CHECK(e.N() == 1 && same(e, MV(f.a.view(1)), tol));
     });
 }
 
@@ -402,6 +442,47 @@ static HipOperatorWrapper op_from_dense(rails_ctx *ctx, std::vector<double> cons
         va.push_back(0.0);
     }
     return HipOperatorWrapper(ctx, n, n, rp.data(), ci.data(), va.data());
+}
+
+// the coordinate-space operator: the same products through materialise / SpMM / absorb
+static void subspace_operator_cases(rails_ctx *ctx)
+{
+    const int n = 10;
+    g_case = "Subspace.Op";
+    auto basis = std::make_shared<SubspaceBasis>(ctx, n, n, 32);
+    std::vector<double> E((size_t)n * n, 0.0);
+    E[0 + 0 * n] = 1;
+    E[0 + 1 * n] = 2;
+    E[1 + 0 * n] = 3;
+    E[1 + 1 * n] = 4;
+    SubspaceOperator A(op_from_dense(ctx, E, n), basis);
+    SubspaceMultiVector a(basis, 1);
+    a.random();
+    double a0 = get(a, 0, 0), a1 = get(a, 1, 0);
+    SubspaceMultiVector b = A * a, bt = A.transpose() * a;
+    CHECK_NEAR(a0 + 2.0 * a1, get(b, 0, 0), 1e-13);
+    CHECK_NEAR(3.0 * a0 + 4.0 * a1, get(b, 1, 0), 1e-13);
+    CHECK_NEAR(0.0, get(b, 5, 0), 1e-13);
+    CHECK_NEAR(a0 + 3.0 * a1, get(bt, 0, 0), 1e-13);
+    CHECK_NEAR(2.0 * a0 + 4.0 * a1, get(bt, 1, 0), 1e-13);
+    CHECK(A.M() == n && A.N() == n);
+    // a wider block, then the basis cannot exceed the dimension of the space
+    SubspaceMultiVector w(basis, 6);
+    w.random();
+    SubspaceMultiVector aw = A * w;
+    std::vector<double> hw = host_of(w), haw = host_of(aw);
+    for (int j = 0; j < 6; ++j) {
+        CHECK_NEAR(hw[0 + (size_t)j * n] + 2.0 * hw[1 + (size_t)j * n], haw[0 + (size_t)j * n], 1e-12);
+        CHECK_NEAR(3.0 * hw[0 + (size_t)j * n] + 4.0 * hw[1 + (size_t)j * n], haw[1 + (size_t)j * n], 1e-12);
+    }
+    SubspaceMultiVector more(basis, 8);
+    more.random();
+    CHECK(basis->dim <= n);
+    HostDenseMatrix G = more.dot(more);
+    std::vector<double> hm = host_of(more);
+    double s01 = 0.0;
+    for (int i = 0; i < n; ++i) s01 += hm[i] * hm[i + n];
+    CHECK_NEAR(s01, G(0, 1), 1e-12);
 }
 
 static void operator_cases(rails_ctx *ctx)
@@ -578,6 +659,7 @@ static void dense_cases()
 int main(int argc, char **argv)
 {
     bool host_only = argc > 1 && std::strcmp(argv[1], "--host") == 0;
+    setvbuf(stdout, nullptr, _IONBF, 0);
     if (rails_host_lapack_init(nullptr) != RAILS_OK) {
         std::printf("no host LAPACK: %s\n", rails_last_error());
         return 2;
@@ -591,8 +673,14 @@ int main(int argc, char **argv)
         }
         rails_ctx_set_seed(ctx, 11, 0);
         rails::set_default_context(ctx);
-        multivector_cases(ctx);
+        HipTraits ht{ctx, 0.0, "MV"};
+        multivector_cases(ht);
         operator_cases(ctx);
+        { // the basis panel must be gone before the context
+            SubspaceTraits st{std::make_shared<SubspaceBasis>(ctx, 10, 10, 32), 2e-14, "SubspaceMV"};
+            multivector_cases(st);
+        }
+        subspace_operator_cases(ctx);
         rails_ctx_destroy(ctx);
     }
     std::printf("%s: %d checks, %d failures\n", host_only ? "host cases" : "all cases", g_checks, g_fail);

@@ -159,7 +159,7 @@ def test_partitioned_spmm_and_reductions(oracle, nranks):
     assert np.array_equal(np.vstack([res[r]["rand"] for r in range(nranks)]), oracle.random(m, 3, mode=1, seed=5, stream=0))
 
 
-@pytest.mark.parametrize("nranks,projected", [(2, 0), (3, 0), (2, 1)])
+@pytest.mark.parametrize("nranks,projected", [(2, 0), (3, 0), (2, 1), (2, 2), (3, 2)])
 def test_partitioned_solve_matches_oracle_and_single_rank(oracle, nranks, projected):
     import rails_amd
     from rails_amd import partition
@@ -179,7 +179,8 @@ def test_partitioned_solve_matches_oracle_and_single_rank(oracle, nranks, projec
         s = rails_amd.Solver(ctx, op, B[r0:r1], m_global=m)
         assert s.set_parameters(params) == 0
         s.set_option("verbose", 0)
-        s.set_option("projected_lanczos", projected)
+        s.set_option("projected_lanczos", 1 if projected == 1 else 0)
+        s.set_option("subspace", 1 if projected == 2 else 0)  # 2: the coordinate-space back end
         code, V, T = s.solve()
         out = dict(code=code, V=V, T=T, hist=s.history(), trips=s.trips(), rel=s.relative_residual(), stats=ctx.stats())
         s.close()
@@ -196,7 +197,7 @@ def test_partitioned_solve_matches_oracle_and_single_rank(oracle, nranks, projec
         assert np.array_equal(res[r]["T"], T)  # replicated
         assert np.array_equal(res[r]["hist"], res[0]["hist"])
         assert res[r]["stats"]["allreduce"] > 0
-        if projected:
+        if projected == 1:
             assert res[r]["stats"]["lanczos_start"] > 0
     assert abs(res[0]["trips"] - out["trips"]) <= 1
     h, ho = res[0]["hist"], out["res_hist"]
@@ -211,7 +212,8 @@ def test_partitioned_solve_matches_oracle_and_single_rank(oracle, nranks, projec
     s = rails_amd.Solver(ctx, rails_amd.HipOperatorWrapper(ctx, *A), B)
     assert s.set_parameters(params) == 0
     s.set_option("verbose", 0)
-    s.set_option("projected_lanczos", projected)
+    s.set_option("projected_lanczos", 1 if projected == 1 else 0)
+    s.set_option("subspace", 1 if projected == 2 else 0)
     code, V1, T1 = s.solve()
     assert code == 0 and abs(s.trips() - res[0]["trips"]) <= 1
     X1 = V1 @ T1 @ V1.T

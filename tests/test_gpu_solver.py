@@ -260,3 +260,81 @@ def test_projected_lanczos_falls_back_with_mass_matrix(ctx, oracle):
     before = ctx.stats()
     _compare_with_oracle(ctx, oracle, A, B, params, 1e-4, seed=9, M=M, options={"projected_lanczos": 1})
     assert ctx.stats()["lanczos_start"] == before["lanczos_start"]
+
+
+# ---- the coordinate-space back end (rails/SubspaceWrappers.hpp, option "subspace") ------------------------------------------
+SUB = {"subspace": 1}
+
+
+def test_subspace_backend_known_answers(ctx):
+    # the reference's KATs (test/LyapunovSolverEpetra_test.cpp:51-177) and n = 20 shapes (test/LyapunovSolver_test.cpp:118-300)
+    A = np.array([[0.0, 1.0], [-5.0, -5.0]])
+    for B, Xexp in ((-np.eye(2), [[0.62, -0.5], [-0.5, 0.6]]), (np.array([[-1.0], [-1.0]]), [[0.82, -0.5], [-0.5, 0.6]])):
+        code, V, T, s = _solve(ctx, A, B, {"Minimize solution space": 0}, options=SUB)
+        assert code == 0 and s.backend_stats()["absorb"] > 0  # the coordinate-space back end really ran
+        np.testing.assert_allclose(V @ T @ V.T, Xexp, rtol=0, atol=1e-13)
+    g = np.random.default_rng(1)
+    n = 20
+    A = g.uniform(-1, 1, (n, n))
+    B = g.uniform(-1, 1, (n, 1))
+    code, V, T, _ = _solve(ctx, A, B, {}, options=SUB)
+    assert code == 0 and np.abs(_residual(A, B, V, T)).max() < 1e-3
+    A, B = _tridiagonal_problem(20, 2)
+    code, V, T, _ = _solve(ctx, A, B, {"Restart Size": 19, "Reduced Size": 15, "Expand Size": 1, "Minimize solution space": 0}, options=SUB)
+    assert code == 0 and V.shape[1] < 20 and np.abs(_residual(A, B, V, T)).max() < 1e-3
+    A, B = _tridiagonal_problem(20, 3)
+    code, V, T, _ = _solve(ctx, A, B, {"Minimize solution space": 0, "Tolerance": 1e-8}, options=SUB)
+    assert code == 0 and V.shape[1] == 20 and np.abs(_residual(A, B, V, T)).max() < 1e-3
+    code, V, T, _ = _solve(ctx, A, B, {"Minimize solution space": 1, "Tolerance": 1e-8}, options=SUB)
+    assert code == 0 and V.shape[1] < 20 and np.abs(_residual(A, B, V, T)).max() < 1e-3
+    A, B = _tridiagonal_problem(20, 4)
+    code, V, T, _ = _solve(ctx, A, B, {"Restart iterations": 10, "Minimize solution space": 0, "Expand size": 1}, options=SUB)
+    assert code == 0 and V.shape[1] < 20 and np.abs(_residual(A, B, V, T)).max() < 1e-3
+
+
+def test_subspace_backend_matches_oracle(ctx, oracle):
+    """Same seeds, same algorithm, every multivector as coordinates in one orthonormal device basis: the trajectory must match the
+    oracle like the direct back end's does (first estimate 1e-9, first trips 1e-6, X to 10*tol), V must come out orthonormal."""
+    from rails_amd import problems as P
+
+    A = P.dense_stable(256, seed=1)
+    B = P.rhs(256, 8, seed=2)
+    params = {"Restart size": 64, "Reduced size": 32, "Expand size": 4, "Lanczos iterations": 8, "Tolerance": 1e-3}
+    V, T, s, out = _compare_with_oracle(ctx, oracle, A, B, params, 1e-3, seed=1, trajectory=True, options=SUB)
+    st = s.backend_stats()
+    assert st["absorb"] > 0 and st["compress"] >= 1
+    assert np.linalg.norm(_residual(A, B, V, T)) / np.linalg.norm(B @ B.T) < 2e-3
+    assert np.abs(V.T @ V - np.eye(V.shape[1])).max() < 1e-12
+    # BASELINE configs[0] parameters (Lanczos iterations past the rank of the residual operator: invariants only)
+    B4 = P.rhs(256, 4, seed=2)
+    params = {"Restart size": 32, "Reduced size": 16, "Expand size": 3, "Lanczos iterations": 10, "Tolerance": 1e-3}
+    V, T, s, out = _compare_with_oracle(ctx, oracle, A, B4, params, 1e-3, seed=1, trajectory=False, options=SUB)
+    assert np.linalg.norm(_residual(A, B4, V, T)) / np.linalg.norm(B4 @ B4.T) < 2e-3
+    # configs[1] at oracle size
+    A = P.laplace7(20, 20, 15)
+    m = A[0].size - 1
+    B = P.rhs(m, 8, seed=5)
+    params = {"Restart size": 64, "Reduced size": 32, "Expand size": 8, "Lanczos iterations": 10, "Tolerance": 1e-3}
+    V, T, s, out = _compare_with_oracle(ctx, oracle, A, B, params, 1e-3, seed=3, trajectory=True, options=SUB)
+    assert s.relative_residual() < 5e-3
+    assert np.abs(V.T @ V - np.eye(V.shape[1])).max() < 1e-12
+    # tight tolerance: no noise floor (unlike the coefficient-space Lanczos of the direct back end)
+    params = {"Restart size": 96, "Reduced size": 48, "Expand size": 8, "Lanczos iterations": 10, "Tolerance": 1e-6}
+    code, V, T, s = _solve(ctx, A, B, params, seed=3, options=SUB)
+    assert code == 0 and s.relative_residual() < 1e-5 and abs(s.trips() - 58) <= 3  # the oracle takes 58 trips
+
+
+def test_subspace_backend_falls_back_for_mass_matrix_and_warm_start(ctx, oracle):
+    from rails_amd import problems as P
+
+    A = P.laplace7(10, 10, 10)
+    m = A[0].size - 1
+    B = P.rhs(m, 4, seed=6)
+    params = {"Restart size": 40, "Reduced size": 20, "Expand size": 4, "Lanczos iterations": 6, "Tolerance": 1e-4}
+    code, V, T, s = _solve(ctx, A, B, params, seed=2, options=SUB)
+    assert code == 0 and s.backend_stats()
+    code, V2, T2, s2 = _solve(ctx, A, B, {**params, "Restart from solution": 1}, seed=2, V0=V, options=SUB)
+    assert code == 0 and s2.backend_stats() == {}  # direct back end
+    M = P.mass_diag(m, seed=4)
+    code, V3, T3, s3 = _solve(ctx, A, B, params, seed=2, M=M, mass=True, options=SUB)
+    assert code == 0 and s3.backend_stats() == {}
