@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--force-hooks", action="store_true", help="single rank: still route every reduction through torch.distributed (RCCL, world size 1)")
     ap.add_argument("--projected-lanczos", type=int, default=0, help="1: coefficient-space residual Lanczos (rails/HipSolverOps.hpp)")
-    ap.add_argument("--subspace", type=int, default=0, help="1: coordinate-space back end (rails/SubspaceWrappers.hpp)")
+    ap.add_argument("--subspace", type=int, default=1, help="1 (default): coordinate-space back end (rails/SubspaceWrappers.hpp); 0: direct panels")
     ap.add_argument("--spmm-only", action="store_true", help="kernel experiment: only the A*X timing, for several column counts")
     ap.add_argument("--spmm-cols", default="128", help="comma list of column counts for --spmm-only")
     ap.add_argument("--spmm-pad", type=int, default=0, help="--spmm-only: extra panel capacity (columns), i.e. a row stride that is not a power of two")

@@ -47,7 +47,7 @@ struct rails_solver {
     rails_trip_fn trip_fn = nullptr;
     void *trip_user = nullptr;
     // coordinate-space back end (rails/SubspaceWrappers.hpp): used by solve() when asked for and applicable
-    bool subspace = false, verbose = true, projected = false;
+    bool subspace = true, verbose = true, projected = false; // default: coordinate-space back end where applicable (M = I, cold start)
     int max_trips = 0;
     bool have_V0 = false;
     bool last_was_subspace = false;
@@ -191,9 +191,11 @@ static int solve_in_coordinates(rails_solver *s)
     s->sub_trips = solver.trips();
     s->sub_hist = solver.residual_history();
     s->sub_profile = solver.profile();
-    char buf[256];
-    snprintf(buf, sizeof(buf), "{\"dim\": %d, \"absorb\": %ld, \"absorb_columns\": %ld, \"one_by_one\": %ld, \"dropped\": %ld, \"compress\": %ld, \"materialise\": %ld}",
-             basis->dim, basis->n_absorb, basis->n_absorb_cols, basis->n_single, basis->n_dropped, basis->n_compress, basis->n_materialise);
+    char buf[768];
+    snprintf(buf, sizeof(buf), "{\"dim\": %d, \"absorb\": %ld, \"absorb_columns\": %ld, \"one_by_one\": %ld, \"dropped\": %ld, \"compress\": %ld, \"materialise\": %ld, \"prefetched_random\": %ld, \"seconds\": {\"materialise\": %.4f, \"absorb\": %.4f, \"compress_qr\": %.4f, \"compress_rotate\": %.4f, "
+             "\"compress_coefficients\": %.4f}}",
+             basis->dim, basis->n_absorb, basis->n_absorb_cols, basis->n_single, basis->n_dropped, basis->n_compress, basis->n_materialise, basis->n_prefetched,
+             basis->t_materialise, basis->t_absorb, basis->t_qr, basis->t_rotate, basis->t_recoef);
     s->sub_stats = buf;
     if (basis->failed) {
         rails_set_error("coordinate-space back end: a device operation failed (%s)", rails_last_error());

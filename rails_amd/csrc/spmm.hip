@@ -1034,6 +1034,9 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
 {
     *done = false;
     if (!vec2 || nc < 8 || A->nnz == 0 || A->m >= 0x7fffffffLL) return RAILS_OK;
+    // the tile plan costs a host analysis of the whole matrix (~0.45 s per million rows): built on first use by a WIDE product
+    // (warm start, the A*V benchmark) or when the kernel is asked for; the narrow in-loop products keep the row-gather kernel
+    if (!A->tiled_ready && nc < 64 && A->variant == 0) return RAILS_OK;
     static const int env_rows = spmm_env("RAILS_SPMM_TILE_ROWS", 64);
     static const int env_kc = spmm_env("RAILS_SPMM_TILE_KC", 8);
     static const int env_box = spmm_env("RAILS_SPMM_TILE_BOX", 1);

@@ -21,7 +21,9 @@
 #define RAILS_SUBSPACEWRAPPERS_HPP
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <memory>
@@ -52,8 +54,34 @@ public:
     int dim = 0;
     int row_cap; // leading dimension of every coefficient store
     std::vector<std::weak_ptr<CoefStore>> live;
-    long n_absorb = 0, n_absorb_cols = 0, n_single = 0, n_compress = 0, n_materialise = 0, n_dropped = 0;
+    long n_absorb = 0, n_absorb_cols = 0, n_single = 0, n_compress = 0, n_materialise = 0, n_dropped = 0, n_prefetched = 0;
     bool failed = false;
+    // The next 1-column random() of the solver (the Lanczos start vector of the coming trip, src/LyapunovSolver.hpp:374) is
+    // drawn ahead of time and expressed in the basis together with the A*W block it follows: one more column in a block
+    // projection instead of two passes over the basis of its own.  The RNG stream it consumes is the one that random() call
+    // would have consumed (streams are handed out in call order and nothing else draws in between).
+    // wall-clock split (seconds); with RAILS_SUBSPACE_PROFILE=1 the device is synchronised around every part so that the numbers
+    // are those of the part itself
+    double t_materialise = 0, t_absorb = 0, t_qr = 0, t_rotate = 0, t_recoef = 0;
+    bool profile_sync = getenv("RAILS_SUBSPACE_PROFILE") != nullptr;
+    struct Tick {
+        SubspaceBasis *b;
+        double *acc;
+        std::chrono::steady_clock::time_point t0;
+        Tick(SubspaceBasis *bb, double *a) : b(bb), acc(a)
+        {
+            if (b->profile_sync) rails_ctx_sync(b->ctx);
+            t0 = std::chrono::steady_clock::now();
+        }
+        ~Tick()
+        {
+            if (b->profile_sync) rails_ctx_sync(b->ctx);
+            *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+    };
+    std::shared_ptr<CoefStore> cached_random;
+    bool cached_valid = false;
+    bool prefetch_random = true;
 
     SubspaceBasis(rails_ctx *c, int64_t ml, int64_t mg, int rows) : ctx(c), m_local(ml), m_global(mg), P(ml, std::max(rows, 16), c), row_cap(std::max(rows, 16))
     {
@@ -89,6 +117,7 @@ public:
         out.set_global_rows(m_global);
         out.resize(n);
         n_materialise++;
+        Tick tick(this, &t_materialise);
         if (n <= 0) return out;
         if (dim == 0) {
             out = 0.0;
@@ -121,6 +150,7 @@ public:
         n_absorb++;
         n_absorb_cols += w;
         if (w <= 0) return true;
+        Tick tick(this, &t_absorb);
         const int ld = row_cap;
         rails_panel *pp = P.panel();
         std::vector<double> G0((size_t)w * w), C((size_t)std::max(dim, 1) * w), G((size_t)w * w);
@@ -208,13 +238,26 @@ public:
             }
         live.swap(still);
         if (dim == 0 || ncols == 0) return;
+        // only columns that hold something take part in the factorisation (capacity columns and discarded ones are zero)
         std::vector<double> Call((size_t)dim * ncols);
         int c0 = 0;
         for (auto &s : stores)
-            for (int j = 0; j < s->ncap; ++j, ++c0) memcpy(Call.data() + (size_t)c0 * dim, s->col(j), sizeof(double) * dim);
+            for (int j = 0; j < s->ncap; ++j) {
+                const double *cj = s->col(j);
+                bool nz = false;
+                for (int i = 0; i < dim && !nz; ++i) nz = cj[i] != 0.0;
+                if (!nz) continue;
+                memcpy(Call.data() + (size_t)c0 * dim, cj, sizeof(double) * dim);
+                ++c0;
+            }
+        ncols = c0;
+        if (ncols == 0) return;
         std::vector<double> Q((size_t)dim * std::min(dim, ncols));
         int rank = 0, info = 0;
-        rails_range_basis(dim, ncols, Call.data(), dim, 1e-14, Q.data(), dim, &rank, &info);
+        {
+            Tick tick(this, &t_qr);
+            rails_range_basis(dim, ncols, Call.data(), dim, 1e-14, Q.data(), dim, &rank, &info);
+        }
         if (info != 0 || rank <= 0 || rank >= dim - 8) return; // nothing (worth it) to drop
         // device: P2 = P * Q
         if (P2.N() < 0 || P2.capacity() < rank + 64) {
@@ -222,19 +265,32 @@ public:
             P2.set_global_rows(m_global);
         }
         P2.resize(rank);
+        Tick *rot = new Tick(this, &t_rotate);
         for (int j0 = 0; j0 < rank; j0 += 256) {
             int nc = std::min(256, rank - j0);
             if (!hip_ok(rails_panel_gemm(ctx, 1.0, P.panel(), 0, dim, Q.data() + (size_t)j0 * dim, dim, nc, 0.0, P2.panel(), j0), "rails_panel_gemm")) {
                 failed = true;
+                delete rot;
                 return;
             }
         }
-        // host: C <- Q' C
-        std::vector<double> tmp((size_t)rank);
+        delete rot;
+        Tick tick(this, &t_recoef);
+        // host: C <- Q' C (columns up to the last non-zero one of every store)
         for (auto &s : stores) {
-            std::vector<double> nc((size_t)rank * s->ncap);
-            rails_dgemm('T', 'N', rank, s->ncap, dim, 1.0, Q.data(), dim, s->c.data(), s->ld, 0.0, nc.data(), rank);
-            for (int j = 0; j < s->ncap; ++j) {
+            int used = 0;
+            for (int j = s->ncap - 1; j >= 0 && !used; --j) {
+                const double *cj = s->col(j);
+                for (int i = 0; i < dim; ++i)
+                    if (cj[i] != 0.0) {
+                        used = j + 1;
+                        break;
+                    }
+            }
+            if (used == 0) continue;
+            std::vector<double> nc((size_t)rank * used);
+            rails_dgemm('T', 'N', rank, used, dim, 1.0, Q.data(), dim, s->c.data(), s->ld, 0.0, nc.data(), rank);
+            for (int j = 0; j < used; ++j) {
                 memcpy(s->col(j), nc.data() + (size_t)j * rank, sizeof(double) * rank);
                 std::fill(s->col(j) + rank, s->col(j) + dim, 0.0);
             }
@@ -497,6 +553,16 @@ public:
             return;
         }
         SubspaceBasis &b = *basis_;
+        orthogonalized_ = 0;
+        if (b.cached_valid) {
+            b.cached_valid = false;
+            if (n_ == 1) { // drawn ahead with the last A*W block
+                memcpy(cptr(0), b.cached_random->col(0), sizeof(double) * ld());
+                std::fill_n(b.cached_random->col(0), b.cached_random->ld, 0.0); // nothing for compress() to keep alive
+                return;
+            }
+            std::cerr << "rails_amd: a prefetched random vector is discarded (random() on " << n_ << " columns)" << std::endl;
+        }
         for (int j0 = 0; j0 < n_; j0 += 64) {
             int w = std::min(64, n_ - j0);
             int t0 = b.tail(w);
@@ -681,13 +747,25 @@ public:
         HipMultiVectorWrapper Xd = X.materialise();
         for (int j0 = 0; j0 < n; j0 += 64) {
             int w = std::min(64, n - j0);
-            int t0 = b.tail(w);
-            b.P.resize(t0 + w);
-            HipMultiVectorWrapper Xw = Xd.view(j0, j0 + w - 1);
-            if (w == 1) Xw = Xd.view(j0);
+            const bool pre = b.prefetch_random && !b.cached_valid && j0 + w == n && w < 64;
+            int t0 = b.tail(w + (pre ? 1 : 0));
+            b.P.resize(t0 + w + (pre ? 1 : 0));
+            HipMultiVectorWrapper Xw = (w == 1) ? Xd.view(j0) : Xd.view(j0, j0 + w - 1);
             if (!A_.apply_into(Xw, b.P, t0)) b.failed = true;
+            if (pre && !hip_ok(rails_panel_random(b.ctx, b.P.panel(), t0 + w, 1), "rails_panel_random")) b.failed = true;
             b.P.resize(t0);
-            b.absorb_tail(w, out.cptr(j0));
+            if (!pre) {
+                b.absorb_tail(w, out.cptr(j0));
+                continue;
+            }
+            // the block [A*W | q] is absorbed as one; its last column's coordinates are kept for the coming random()
+            std::vector<double> coef((size_t)b.row_cap * (w + 1), 0.0);
+            b.absorb_tail(w + 1, coef.data());
+            for (int j = 0; j < w; ++j) memcpy(out.cptr(j0 + j), coef.data() + (size_t)j * b.row_cap, sizeof(double) * b.row_cap);
+            if (!b.cached_random || b.cached_random->ld != b.row_cap) b.cached_random = b.new_store(1, true);
+            memcpy(b.cached_random->col(0), coef.data() + (size_t)w * b.row_cap, sizeof(double) * b.row_cap);
+            b.cached_valid = true;
+            b.n_prefetched++;
         }
         return out;
     }

@@ -33,7 +33,8 @@ def main(argv=None):
     ap.add_argument("--T", default="T.mtx")
     ap.add_argument("--warm-start", default=None, help="V.mtx of a previous solve (orthonormal columns): sets 'Restart from solution'")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE", help="override one solver parameter, e.g. --set 'Tolerance=1e-6'")
-    ap.add_argument("--projected-lanczos", action="store_true", help="coefficient-space residual Lanczos (M = I only)")
+    ap.add_argument("--direct", action="store_true", help="direct back end (device panels for V, AV) instead of the default coordinate-space back end")
+    ap.add_argument("--projected-lanczos", action="store_true", help="direct back end with the coefficient-space residual Lanczos (M = I only)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args(argv)
@@ -112,6 +113,8 @@ def main(argv=None):
     solver.set_option("verbose", 0 if (args.quiet or rank != 0) else 1)
     if Mop is not None:
         solver.set_option("mass", 1)
+    if args.direct or args.projected_lanczos:
+        solver.set_option("subspace", 0)
     if args.projected_lanczos and Mop is None:
         solver.set_option("projected_lanczos", 1)
 

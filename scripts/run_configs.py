@@ -30,6 +30,7 @@ def run(ctx, name, A, B, params, M=None, V0=None, max_trips=400, seed=1):
     s.set_option("max_trips", max_trips)
     if M is None and os.environ.get("RAILS_RUN_PROJECTED", "0") == "1":
         s.set_option("projected_lanczos", 1)
+    s.set_option("subspace", 1 if os.environ.get("RAILS_RUN_SUBSPACE", "0") == "1" else 0)
     if M is not None:
         s.set_option("mass", 1)
     ctx.sync()
@@ -39,7 +40,7 @@ def run(ctx, name, A, B, params, M=None, V0=None, max_trips=400, seed=1):
     dt = time.perf_counter() - t0
     rel = s.relative_residual()
     out = {"config": name, "m": int(A[0].size - 1), "p": int(B.shape[1]), "params": params, "code": code, "trips": s.trips(), "seconds": dt,
-           "iterations_per_s": s.trips() / dt, "residual_lanczos": "projected" if (M is None and os.environ.get("RAILS_RUN_PROJECTED", "0") == "1") else "fused", "k_final": s.k, "relative_residual": rel, "host_sections": s.profile(), "spmm_kernel": op.last_kernel(), "counters_cumulative": ctx.stats()}
+           "iterations_per_s": s.trips() / dt, "residual_lanczos": "projected" if (M is None and os.environ.get("RAILS_RUN_PROJECTED", "0") == "1") else "fused", "k_final": s.k, "relative_residual": rel, "host_sections": s.profile(), "backend": s.backend_stats(), "spmm_kernel": op.last_kernel(), "counters_cumulative": ctx.stats()}
     print(json.dumps(out), flush=True)
     return s, op
 

@@ -56,9 +56,19 @@ def test_allreduce_hook_over_rccl_single_rank(oracle):
         sv = rails_amd.Solver(ctx, op, B)
         assert sv.set_parameters(params) == 0
         sv.set_option("verbose", 0)
+        sv.set_option("subspace", 0)  # direct back end: one all-reduce per Lanczos step + projections
         n0 = len(calls)
         code, V, T = sv.solve()
-        assert code == 0 and len(calls) - n0 > 9 * sv.trips()  # one all-reduce per Lanczos step + projections
+        assert code == 0 and len(calls) - n0 > 9 * sv.trips()
+        # the default (coordinate-space) back end through the same hook: a handful of block reductions per trip
+        ctx.set_seed(11, 0)
+        sv.set_option("subspace", 1)
+        n1 = len(calls)
+        code, V2, T2 = sv.solve()
+        assert code == 0 and sv.backend_stats()["absorb"] > 0 and 0 < len(calls) - n1 < 12 * sv.trips()
+        X2 = V2 @ T2 @ V2.T
+        Xd = V @ T @ V.T
+        assert np.linalg.norm(X2 - Xd) / np.linalg.norm(Xd) < 1e-4
         out = oracle.solve(A, B, oracle.params({**params, "rng_mode": 1, "seed": 11}))
         Xg, Xo = V @ T @ V.T, out["V"] @ out["T"] @ out["V"].T
         assert np.linalg.norm(Xg - Xo) / np.linalg.norm(Xo) < 1e-4

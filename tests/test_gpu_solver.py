@@ -33,7 +33,9 @@ def _solve(ctx, A, B, params, seed=1, M=None, V0=None, mass=False, options=None)
     s.set_option("verbose", 0)
     if mass:
         s.set_option("mass", 1)
-    for name, value in (options or {}).items():
+    opts = {"subspace": 0}  # these tests address the direct back end unless a test says otherwise (SUB below)
+    opts.update(options or {})
+    for name, value in opts.items():
         s.set_option(name, value)
     code, V, T = s.solve(V0=V0)
     return code, V, T, s
