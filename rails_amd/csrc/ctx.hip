@@ -48,6 +48,7 @@ extern "C" int rails_ctx_create(int device, void *stream, rails_ctx **out)
     }
     RAILS_HIP_CHECK(hipEventCreate(&c->ev0));
     RAILS_HIP_CHECK(hipEventCreate(&c->ev1));
+    RAILS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
     *out = c;
     return RAILS_OK;
 }
@@ -63,6 +64,7 @@ extern "C" int rails_ctx_destroy(rails_ctx *c)
     if (c->pinned) hipHostFree(c->pinned);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return RAILS_OK;
@@ -166,6 +168,22 @@ static int grow(rails_ctx *c, double **p, size_t *have, size_t need, bool host)
 int rails_ws_reserve(rails_ctx *c, size_t bytes) { return grow(c, &c->ws, &c->ws_bytes, bytes, false); }
 int rails_small_reserve(rails_ctx *c, size_t bytes) { return grow(c, &c->small, &c->small_bytes, bytes, false); }
 int rails_pinned_reserve(rails_ctx *c, size_t bytes) { return grow(c, &c->pinned, &c->pinned_bytes, bytes, true); }
+
+int rails_pinned_begin_write(rails_ctx *c, size_t bytes)
+{
+    if (c->h2d_pending) {
+        RAILS_HIP_CHECK(hipEventSynchronize(c->ev_h2d));
+        c->h2d_pending = false;
+    }
+    return rails_pinned_reserve(c, bytes);
+}
+
+int rails_pinned_end_write(rails_ctx *c)
+{
+    RAILS_HIP_CHECK(hipEventRecord(c->ev_h2d, c->stream));
+    c->h2d_pending = true;
+    return RAILS_OK;
+}
 
 extern "C" int rails_timer_start(rails_ctx *c)
 {

@@ -316,12 +316,12 @@ extern "C" int rails_panel_gemm(rails_ctx *c, double alpha, const rails_panel *X
         return rails_panel_scale(c, Y, yc0, r, beta);
     }
     size_t n = (size_t)k * r;
+    // asynchronous: the coefficient block goes through the pinned staging buffer (the next host write into it waits for this
+    // upload, rails_pinned_begin_write) into the context's small device buffer (re-used in stream order)
     RAILS_TRY(rails_small_reserve(c, n * sizeof(double)));
-    RAILS_TRY(rails_pinned_reserve(c, n * sizeof(double)));
+    RAILS_TRY(rails_pinned_begin_write(c, n * sizeof(double)));
     for (int j = 0; j < r; ++j) memcpy(c->pinned + (size_t)j * k, C_host + (size_t)j * ldc, sizeof(double) * k);
     RAILS_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    RAILS_TRY(rails_panel_gemm_dev(c, alpha, X->d + xc0, X->ld, k, c->small, r, beta, Y->d + yc0, Y->ld, X->m));
-    // the pinned staging buffer is reused by the next call: make sure the copy has been consumed
-    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return RAILS_OK;
+    RAILS_TRY(rails_pinned_end_write(c));
+    return rails_panel_gemm_dev(c, alpha, X->d + xc0, X->ld, k, c->small, r, beta, Y->d + yc0, Y->ld, X->m);
 }

@@ -516,7 +516,7 @@ static int lz_run(rails_ctx *c, const rails_panel *AV, int avc0, const rails_pan
     double *dalpha = dstate + 8;
     double *dbeta = dalpha + (L + 2);
     RAILS_TRY(rails_ws_reserve(c, (size_t)nblocks * ncoef * sizeof(double)));
-    RAILS_TRY(rails_pinned_reserve(c, std::max<size_t>((size_t)k * k, (size_t)(2 * (L + 2) + 8)) * sizeof(double)));
+    RAILS_TRY(rails_pinned_begin_write(c, std::max<size_t>((size_t)k * k, (size_t)(2 * (L + 2) + 8)) * sizeof(double)));
     // T -> device (contiguous k x k)
     if (!only_start) {
         for (int j = 0; j < k; ++j) memcpy(c->pinned + (size_t)j * k, T_host + (size_t)j * ldt, sizeof(double) * k);
@@ -615,7 +615,7 @@ extern "C" int rails_lanczos_vectors(rails_ctx *c, const double *S_host, int lds
     const int steps = S.steps;
     size_t n = (size_t)steps * w;
     RAILS_TRY(rails_small_reserve(c, n * sizeof(double)));
-    RAILS_TRY(rails_pinned_reserve(c, n * sizeof(double)));
+    RAILS_TRY(rails_pinned_begin_write(c, n * sizeof(double)));
     for (int j = 0; j < w; ++j) memcpy(c->pinned + (size_t)j * steps, S_host + (size_t)j * lds, sizeof(double) * steps);
     RAILS_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     for (int j0 = 0; j0 < w; j0 += 16) {

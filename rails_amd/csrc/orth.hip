@@ -31,7 +31,7 @@ int sync_small_to_host(rails_ctx *c, size_t n, std::vector<double> &out)
 
 int upload_small(rails_ctx *c, const std::vector<double> &in, double *dst)
 {
-    RAILS_TRY(rails_pinned_reserve(c, in.size() * sizeof(double)));
+    RAILS_TRY(rails_pinned_begin_write(c, in.size() * sizeof(double)));
     memcpy(c->pinned, in.data(), in.size() * sizeof(double));
     RAILS_HIP_CHECK(hipMemcpyAsync(dst, c->pinned, in.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -65,6 +65,8 @@ struct rails_ctx {
     size_t pinned_bytes = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_h2d = nullptr; // recorded after an asynchronous upload out of `pinned`; waited for before the host writes there again
+    bool h2d_pending = false;
     // counters (rails_ctx_stats)
     void *lz = nullptr; // rails_lanczos_state (lanczos.hip), released by rails_lanczos_release
     long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_rowgather = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0;
@@ -125,6 +127,10 @@ struct rails_csr {
 int rails_ws_reserve(rails_ctx *ctx, size_t bytes);
 int rails_small_reserve(rails_ctx *ctx, size_t bytes);
 int rails_pinned_reserve(rails_ctx *ctx, size_t bytes);
+// host -> pinned -> device staging without a stream synchronisation: begin_write waits until the previous upload out of the
+// pinned buffer has been consumed (and reserves), end_write marks the upload just enqueued
+int rails_pinned_begin_write(rails_ctx *ctx, size_t bytes);
+int rails_pinned_end_write(rails_ctx *ctx);
 int rails_allreduce_dev(rails_ctx *ctx, double *dev, size_t n);
 
 // ---- kernels / launchers across translation units ----

@@ -110,12 +110,18 @@ public:
         row_cap = ncap;
     }
 
-    // P(:, 0:dim) * C  (C host, dim x n, ldc) -> new device multivector m x n
+    // P(:, 0:dim) * C  (C host, dim x n, ldc) -> device multivector m x n.  The result aliases a scratch panel of the basis that the
+    // next materialise() call overwrites (no device allocation per call); copy() it to keep it.
+    HipMultiVectorWrapper scratch;
     HipMultiVectorWrapper materialise(const double *C, int ldc, int n)
     {
-        HipMultiVectorWrapper out(m_local, std::max(n, 1), ctx);
-        out.set_global_rows(m_global);
-        out.resize(n);
+        if (scratch.N() < 0 || scratch.capacity() < std::max(n, 1)) {
+            scratch = HipMultiVectorWrapper(m_local, std::max(n, 16), ctx);
+            scratch.set_global_rows(m_global);
+        }
+        scratch.resize(n);
+        HipMultiVectorWrapper out;
+        out = scratch; // shares the panel
         n_materialise++;
         Tick tick(this, &t_materialise);
         if (n <= 0) return out;
@@ -266,8 +272,8 @@ public:
         }
         P2.resize(rank);
         Tick *rot = new Tick(this, &t_rotate);
-        for (int j0 = 0; j0 < rank; j0 += 256) {
-            int nc = std::min(256, rank - j0);
+        for (int j0 = 0; j0 < rank; j0 += 128) { // 128 output columns per launch: the faster tile shape of k_panel_gemm
+            int nc = std::min(128, rank - j0);
             if (!hip_ok(rails_panel_gemm(ctx, 1.0, P.panel(), 0, dim, Q.data() + (size_t)j0 * dim, dim, nc, 0.0, P2.panel(), j0), "rails_panel_gemm")) {
                 failed = true;
                 delete rot;

@@ -18,9 +18,15 @@ def short(name):
     return name.split("(")[0]
 
 
+def newest(pattern):
+    """gpurun_out/ keeps the files of earlier calls: only the most recent run of a directory counts"""
+    fs = glob.glob(pattern, recursive=True)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+
 def pmc(path):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(path, "**", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
@@ -34,7 +40,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     lines = ["# rocprofv3 summary %s (%s)" % (tag, pattern), ""]
     # ---- kernel stats of the default bench command -------------------------------------------------------
-    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, pattern)))
         rows = list(csv.DictReader(open(stats[0])))
