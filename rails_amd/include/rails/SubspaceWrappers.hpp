@@ -159,22 +159,48 @@ public:
         Tick tick(this, &t_absorb);
         const int ld = row_cap;
         rails_panel *pp = P.panel();
-        std::vector<double> G0((size_t)w * w), C((size_t)std::max(dim, 1) * w), G((size_t)w * w);
-        if (!hip_ok(rails_gram(ctx, pp, dim, w, pp, dim, w, G0.data(), w), "rails_gram")) return fail();
-        bool second = true;
-        for (int round = 0; round < 2 && dim > 0; ++round) {
-            if (round == 1 && !second) break;
-            if (!hip_ok(rails_gram(ctx, pp, 0, dim, pp, dim, w, C.data(), dim), "rails_gram")) return fail();
-            if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, C.data(), dim, w, 1.0, pp, dim), "rails_panel_gemm")) return fail();
+        // one Gram call per round gives both the projections P'X (first dim rows) and the block's own Gram matrix X'X (last w rows):
+        // X sits right behind P in the same panel
+        const int dw = dim + w;
+        std::vector<double> CG((size_t)dw * w), G0((size_t)w * w), G((size_t)w * w);
+        bool have_G = false;
+        for (int round = 0; round < 2; ++round) {
+            if (!hip_ok(rails_gram(ctx, pp, 0, dw, pp, dim, w, CG.data(), dw), "rails_gram")) return fail();
             for (int j = 0; j < w; ++j)
-                for (int i = 0; i < dim; ++i) coef[i + (size_t)j * ld] += C[i + (size_t)j * dim];
-            if (round == 0 && w == 1) { // "twice is enough": a second projection only when the first one cancelled digits
+                for (int i = 0; i < w; ++i) (round == 0 ? G0 : G)[i + (size_t)j * w] = CG[(dim + i) + (size_t)j * dw];
+            if (dim == 0) {
+                G = G0;
+                have_G = true;
+                break;
+            }
+            if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, CG.data(), dw, w, 1.0, pp, dim), "rails_panel_gemm")) return fail();
+            double worst = 1.0; // smallest fraction of a column's squared norm that survives the projection
+            for (int j = 0; j < w; ++j) {
                 double c2 = 0.0;
-                for (int i = 0; i < dim; ++i) c2 += C[i] * C[i];
-                second = !(c2 < 0.25 * G0[0]);
+                for (int i = 0; i < dim; ++i) {
+                    const double c = CG[i + (size_t)j * dw];
+                    coef[i + (size_t)j * ld] += c;
+                    c2 += c * c;
+                }
+                const double g = (round == 0 ? G0 : G)[j + (size_t)j * w];
+                worst = std::min(worst, g > 0.0 ? 1.0 - c2 / g : 0.0);
+            }
+            if (round == 0) {
+                // "twice is enough": the second projection repairs the orthogonality lost to cancellation in the first one (a
+                // relative eps * ||x|| / ||x - P P'x||); where more than a hundredth of every column survives there is nothing to repair
+                if (worst > 0.01) break;
+            } else {
+                // after the second round the block's Gram matrix is the one just measured minus the (tiny) second correction
+                for (int j = 0; j < w; ++j)
+                    for (int i = 0; i < w; ++i) {
+                        double s2 = 0.0;
+                        for (int l = 0; l < dim; ++l) s2 += CG[l + (size_t)i * dw] * CG[l + (size_t)j * dw];
+                        G[i + (size_t)j * w] -= s2;
+                    }
+                have_G = true;
             }
         }
-        if (!hip_ok(rails_gram(ctx, pp, dim, w, pp, dim, w, G.data(), w), "rails_gram")) return fail();
+        if (!have_G && !hip_ok(rails_gram(ctx, pp, dim, w, pp, dim, w, G.data(), w), "rails_gram")) return fail();
         // columns that (numerically) lie in span(P): nothing new to add
         std::vector<int> keep;
         for (int j = 0; j < w; ++j) {
