@@ -36,6 +36,28 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# Rank 0 must print ONE JSON line on stdout.  Libraries underneath (RCCL prints a version banner at communicator creation) write
+# to file descriptor 1 themselves, so fd 1 is pointed at stderr for the whole run and the result lines go to the saved descriptor.
+_STDOUT_FD = None
+
+
+def _protect_stdout():
+    global _STDOUT_FD
+    if _STDOUT_FD is None:
+        sys.stdout.flush()
+        _STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _STDOUT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_STDOUT_FD, data)
+
+
 def build_problem(args, rank, nranks):
     from rails_amd import problems as P
 
@@ -93,6 +115,7 @@ def main():
     ap.add_argument("--spmm-cols", default="128", help="comma list of column counts for --spmm-only")
     ap.add_argument("--spmm-pad", type=int, default=0, help="--spmm-only: extra panel capacity (columns), i.e. a row stride that is not a power of two")
     args = ap.parse_args()
+    _protect_stdout()
 
     import torch
 
@@ -163,8 +186,8 @@ def main():
                     A.apply(X, Y)
                 ms = ctx.timer_stop() / args.spmm_reps
                 ab = nnz_local * 12 + (ml + 1) * 4 + 2 * ml * kk * 8
-                print(json.dumps({"pattern": args.pattern, "kernel": A.last_kernel(), "variant": variant, "k": kk, "pad": args.spmm_pad, "ms": ms,
-                                  "alg_GBs": ab / ms / 1e6, "frac": ab / ms / 1e6 / HBM_PEAK_GBS}), flush=True)
+                emit({"pattern": args.pattern, "kernel": A.last_kernel(), "variant": variant, "k": kk, "pad": args.spmm_pad, "ms": ms,
+                      "alg_GBs": ab / ms / 1e6, "frac": ab / ms / 1e6 / HBM_PEAK_GBS})
             del X, Y
         return
 
@@ -279,7 +302,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
     solver.close()
     if dist is not None:
         dist.barrier()

@@ -9,4 +9,4 @@ timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.
 timeout -k 10 400 python bench.py --no-cpu > $O/bench_q.json 2> $O/bench_q.err; tail -3 $O/bench_q.err | cut -c1-700
 timeout -k 10 400 python bench.py --no-cpu --pattern stencil27 > $O/bench_qs.json 2> $O/bench_qs.err; tail -1 $O/bench_qs.err | cut -c1-300
 timeout -k 10 400 python bench.py --no-cpu --force-hooks > $O/bench_qh.json 2> $O/bench_qh.err; tail -1 $O/bench_qh.err | cut -c1-300
-bash scripts/gpu_exp_cfg2.sh
+bash scripts/gpu_configs_both.sh
