@@ -7,7 +7,7 @@
 #include <vector>
 
 #include "rails/HipSolverOps.hpp"
-#include "rails/SubspaceWrappers.hpp"
+#include "rails/SubspaceSolverOps.hpp"
 #include "rails_solver.h"
 
 void rails_set_error(const char *fmt, ...);

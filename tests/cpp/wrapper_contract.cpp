@@ -19,7 +19,7 @@
 #include <vector>
 
 #include "rails/HipSolverOps.hpp"
-#include "rails/SubspaceWrappers.hpp"
+#include "rails/SubspaceSolverOps.hpp"
 
 using rails::HipMultiVectorWrapper;
 using rails::HipOperatorWrapper;

@@ -10,6 +10,7 @@
 #include "src/LyapunovSolver.hpp"
 
 #include "rails/HipWrappers.hpp"
+#include "rails/SubspaceWrappers.hpp"
 
 struct ParameterList { // the mock of test/LyapunovSolver_test.cpp:160-179
     std::map<std::string, double> p;
@@ -33,4 +34,18 @@ int use(rails::HipOperatorWrapper const &A, rails::HipMultiVectorWrapper const &
     rails::HipMultiVectorWrapper V;
     rails::HostDenseMatrix T;
     return with_multivector_B.solve(V, T) + with_operator_B.solve(V, T);
+}
+
+// the coordinate-space back end: the same contract, a different representation (rails/SubspaceWrappers.hpp)
+typedef RAILS::Solver<rails::SubspaceOperator, rails::SubspaceMultiVector, rails::HostDenseMatrix> RefSolverOnSubspace;
+template class RAILS::Solver<rails::SubspaceOperator, rails::SubspaceMultiVector, rails::HostDenseMatrix>;
+
+int use_subspace(rails::SubspaceOperator const &A, rails::SubspaceMultiVector const &B)
+{
+    RefSolverOnSubspace solver(A, B, A);
+    ParameterList params;
+    solver.set_parameters(params);
+    rails::SubspaceMultiVector V;
+    rails::HostDenseMatrix T;
+    return solver.solve(V, T);
 }
