@@ -33,9 +33,9 @@ int rails_solver_set_parameter(rails_solver *s, const char *name, double value);
 int rails_solver_apply_parameters(rails_solver *s, int *code);
 
 /* extensions: "mass" (use M, generalized equation), "verbose", "max_trips", "projected_lanczos" (M = I only: carry the
- * residual Lanczos recurrence in coefficient space, see rails/HipSolverOps.hpp), "subspace" (default 1; M = I, cold start: run the same
- * solver template on the coordinate-space back end of rails/SubspaceWrappers.hpp -- all multivectors as coordinates in one
- * orthonormal device basis; 0 or a mass matrix / warm start: the direct back end of rails/HipWrappers.hpp) */
+ * residual Lanczos recurrence in coefficient space, see rails/HipSolverOps.hpp), "subspace" (default 1: run the solver template on the
+ * coordinate-space back end of rails/SubspaceWrappers.hpp -- all multivectors as coordinates in one orthonormal device basis;
+ * 0: the direct back end of rails/HipWrappers.hpp) */
 int rails_solver_set_option(rails_solver *s, const char *name, double value);
 /* called at the start of every loop trip with the index of that trip, and once after the last */
 typedef void (*rails_trip_fn)(void *user, int trip);

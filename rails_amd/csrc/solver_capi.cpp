@@ -178,13 +178,19 @@ static int solve_in_coordinates(rails_solver *s)
     auto basis = std::make_shared<rails::SubspaceBasis>(s->ctx, s->m_local, s->m_global, 2 * kmax + p + 128);
     rails::SubspaceMultiVector Bc = rails::SubspaceMultiVector::Absorb(basis, s->B);
     rails::SubspaceOperator Ac(s->A, basis);
-    rails::SubspaceSolver solver(Ac, Bc, Ac);
+    rails::SubspaceOperator Mc(s->mass ? s->M : s->A, basis);
+    rails::SubspaceSolver solver(Ac, Bc, Mc);
     int prc = solver.set_parameters(s->params);
     if (prc != 0) return prc + 100;
     solver.set_verbose(s->verbose);
     solver.set_max_trips(s->max_trips);
+    solver.use_mass_matrix(s->mass);
     if (s->trip_fn) solver.set_trip_callback([s](int trip) { s->trip_fn(s->trip_user, trip); });
     rails::SubspaceMultiVector Vc(basis, 1);
+    if (s->have_V0) { // warm start: the caller's (orthonormal) V expressed in the basis (src/LyapunovSolver.hpp:116-123)
+        Vc = rails::SubspaceMultiVector::Absorb(basis, s->V);
+        Vc.set_orthogonalized(Vc.N());
+    }
     int rc = solver.solve(Vc, s->T);
     s->V = Vc.materialise();
     s->V.set_orthogonalized(s->V.N());
@@ -208,13 +214,16 @@ extern "C" int rails_solver_solve(rails_solver *s, int *code, int *k)
 {
     if (!s) return RAILS_EINVAL;
     const bool restart_from_solution = s->params.get("Restart from solution", 0.0) != 0.0;
-    s->last_was_subspace = s->subspace && !s->mass && !s->have_V0 && !restart_from_solution;
+    // a warm start needs the caller's V; "Restart from solution" without one is the direct back end's business (it starts from
+    // the single column the solver object holds, like the reference)
+    s->last_was_subspace = s->subspace && (s->have_V0 || !restart_from_solution);
     int rc;
     if (s->last_was_subspace) {
         rc = solve_in_coordinates(s);
         if (rc == -1000) return RAILS_EHIP;
     } else
         rc = s->solver->solve(s->V, s->T);
+    s->have_V0 = false; // V now holds the result; a later warm start passes its V again (or runs on the direct back end)
     if (code) *code = rc;
     if (k) *k = s->V.N();
     if (rails_ctx_sync(s->ctx) != RAILS_OK) return RAILS_EHIP;

@@ -16,7 +16,7 @@
 //
 // The classes satisfy the same duck-typed contract as HipMultiVectorWrapper / HipOperatorWrapper, so the
 // unmodified solver template -- the reference's member-by-member sequence, src/LyapunovSolver.hpp:100-482 -- runs on them.
-// Not covered: warm starts from a user V, mass matrices (the C API falls back to the direct back end).
+// A mass matrix is one more SubspaceOperator (M * W is absorbed like A * W); a warm start absorbs the caller's V.
 #ifndef RAILS_SUBSPACEWRAPPERS_HPP
 #define RAILS_SUBSPACEWRAPPERS_HPP
 

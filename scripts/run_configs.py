@@ -40,7 +40,7 @@ def run(ctx, name, A, B, params, M=None, V0=None, max_trips=400, seed=1):
     dt = time.perf_counter() - t0
     rel = s.relative_residual()
     out = {"config": name, "m": int(A[0].size - 1), "p": int(B.shape[1]), "params": params, "code": code, "trips": s.trips(), "seconds": dt,
-           "iterations_per_s": s.trips() / dt, "residual_lanczos": "projected" if (M is None and os.environ.get("RAILS_RUN_PROJECTED", "0") == "1") else "fused", "k_final": s.k, "relative_residual": rel, "host_sections": s.profile(), "backend": s.backend_stats(), "spmm_kernel": op.last_kernel(), "counters_cumulative": ctx.stats()}
+           "iterations_per_s": s.trips() / dt, "k_final": s.k, "relative_residual": rel, "host_sections": s.profile(), "backend": s.backend_stats(), "spmm_kernel": op.last_kernel(), "counters_cumulative": ctx.stats()}
     print(json.dumps(out), flush=True)
     return s, op
 

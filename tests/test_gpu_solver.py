@@ -326,17 +326,46 @@ def test_subspace_backend_matches_oracle(ctx, oracle):
     assert code == 0 and s.relative_residual() < 1e-5 and abs(s.trips() - 58) <= 3  # the oracle takes 58 trips
 
 
-def test_subspace_backend_falls_back_for_mass_matrix_and_warm_start(ctx, oracle):
+def test_subspace_backend_mass_matrix_and_warm_start(ctx, oracle):
+    """generalized equation (M * W absorbed like A * W) and warm start (the caller's V absorbed) on the coordinate-space back end"""
     from rails_amd import problems as P
+    import scipy.sparse as sp
 
-    A = P.laplace7(10, 10, 10)
+    A = P.laplace7(12, 12, 10)
     m = A[0].size - 1
-    B = P.rhs(m, 4, seed=6)
-    params = {"Restart size": 40, "Reduced size": 20, "Expand size": 4, "Lanczos iterations": 6, "Tolerance": 1e-4}
-    code, V, T, s = _solve(ctx, A, B, params, seed=2, options=SUB)
-    assert code == 0 and s.backend_stats()
-    code, V2, T2, s2 = _solve(ctx, A, B, {**params, "Restart from solution": 1}, seed=2, V0=V, options=SUB)
-    assert code == 0 and s2.backend_stats() == {}  # direct back end
     M = P.mass_diag(m, seed=4)
-    code, V3, T3, s3 = _solve(ctx, A, B, params, seed=2, M=M, mass=True, options=SUB)
-    assert code == 0 and s3.backend_stats() == {}
+    B = P.rhs(m, 6, seed=6)
+    params = {"Restart size": 60, "Reduced size": 30, "Expand size": 4, "Lanczos iterations": 8, "Tolerance": 1e-4}
+    V, T, s, out = _compare_with_oracle(ctx, oracle, A, B, params, 1e-4, seed=9, M=M, options=SUB)
+    assert s.backend_stats()["absorb"] > 0
+    As = sp.csr_matrix((A[2], A[1], A[0]), shape=(m, m))
+    Md = M[2]
+    X = V @ T @ V.T
+    R = As @ X * Md[None, :] + (Md[:, None] * X) @ As.T + B @ B.T
+    assert np.linalg.norm(R) / np.linalg.norm(B @ B.T) < 2e-3
+    assert abs(s.relative_residual() - np.linalg.norm(R) / np.linalg.norm(B @ B.T)) < 1e-8
+    # tridiagonal SPD mass matrix: M * W needs ghost-free but non-diagonal products
+    Mt = P.mass_tridiag(m)
+    code, V2, T2, s2 = _solve(ctx, A, B, params, seed=9, M=Mt, mass=True, options=SUB)
+    code_d, V3, T3, s3 = _solve(ctx, A, B, params, seed=9, M=Mt, mass=True)
+    assert code == code_d == 0 and s2.backend_stats()["absorb"] > 0 and s3.backend_stats() == {}
+    X2, X3 = V2 @ T2 @ V2.T, V3 @ T3 @ V3.T
+    assert np.linalg.norm(X2 - X3) / np.linalg.norm(X3) < 1e-3
+    # warm start (test/LyapunovSolver_test.cpp:333-341 shape): perturb A's diagonal by 1 %, restart from the previous V
+    A1 = P.laplace7(10, 10, 10)
+    m1 = A1[0].size - 1
+    B1 = P.rhs(m1, 4, seed=6)
+    prm = {"Restart size": 40, "Reduced size": 20, "Expand size": 4, "Lanczos iterations": 6, "Tolerance": 1e-4}
+    code, Va, Ta, sa = _solve(ctx, A1, B1, prm, seed=2, options=SUB)
+    assert code == 0
+    rowptr, col, val = A1
+    val2 = val.copy()
+    val2[col == np.repeat(np.arange(m1), np.diff(rowptr))] *= 1.01
+    A2 = (rowptr, col, val2)
+    code, Vb, Tb, sb = _solve(ctx, A2, B1, {**prm, "Restart from solution": 1}, seed=3, V0=Va, options=SUB)
+    assert code == 0 and sb.backend_stats()["absorb"] > 0 and sb.trips() < sa.trips()
+    code, Vc, Tc, sc = _solve(ctx, A2, B1, {**prm, "Restart from solution": 1}, seed=3, V0=Va)  # direct back end
+    assert code == 0 and abs(sb.trips() - sc.trips()) <= 2
+    Xb, Xc = Vb @ Tb @ Vb.T, Vc @ Tc @ Vc.T
+    assert np.linalg.norm(Xb - Xc) / np.linalg.norm(Xc) < 1e-2
+    assert sb.relative_residual() < 1e-3
