@@ -485,6 +485,63 @@ static void subspace_operator_cases(rails_ctx *ctx)
     CHECK_NEAR(s01, G(0, 1), 1e-12);
 }
 
+// the basis machinery itself: degenerate blocks, growth past the initial capacities, compress()
+static void subspace_basis_cases(rails_ctx *ctx)
+{
+    const int m = 300;
+    g_case = "Subspace.Basis degenerate block";
+    {
+        auto basis = std::make_shared<SubspaceBasis>(ctx, m, m, 16); // small on purpose: rows and panel columns must grow
+        HipMultiVectorWrapper X(m, 6, ctx);
+        X.random();
+        std::vector<double> h = host_of(X);
+        // columns 0,1 random; 2 = 0 + 1; 3 = copy of 0; 4 random; 5 = 1e-9 * random + column 4 (nearly dependent)
+        for (int i = 0; i < m; ++i) {
+            h[i + 2 * (size_t)m] = h[i] + h[i + (size_t)m];
+            h[i + 3 * (size_t)m] = h[i];
+            h[i + 5 * (size_t)m] = h[i + 4 * (size_t)m] + 1e-9 * h[i + 5 * (size_t)m];
+        }
+        X.from_host(h.data(), m);
+        SubspaceMultiVector c = SubspaceMultiVector::Absorb(basis, X);
+        CHECK(basis->dim == 4 && basis->n_single == 1); // 3 independent directions + the 1e-9 one; taken column by column
+        CHECK(same(c.materialise(), X, 1e-13));
+        CHECK(orthonormal(basis->P));
+        // the same vectors again: nothing new
+        SubspaceMultiVector c2 = SubspaceMultiVector::Absorb(basis, X);
+        CHECK(basis->dim == 4);
+        CHECK(same(c2.materialise(), X, 1e-13));
+    }
+    g_case = "Subspace.Basis growth and compress";
+    {
+        auto basis = std::make_shared<SubspaceBasis>(ctx, m, m, 16);
+        SubspaceMultiVector a(basis, 20), b(basis, 30);
+        a.random(); // 20 new directions: past the 16 rows / 16 panel columns the basis started with
+        b.random();
+        CHECK(basis->dim == 50 && basis->row_cap >= 50);
+        HipMultiVectorWrapper A0 = a.materialise().copy(), B0 = b.materialise().copy();
+        CHECK(orthonormal(basis->P));
+        HostDenseMatrix G = a.dot(b);
+        std::vector<double> ha = host_of(A0), hb = host_of(B0);
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s += ha[i + 3 * (size_t)m] * hb[i + 7 * (size_t)m];
+        CHECK_NEAR(s, G(3, 7), 1e-12);
+        // drop most of b, compress: the basis shrinks to what is alive, the survivors are unchanged
+        b.resize(5);
+        b.discard_unused_columns();
+        SubspaceMultiVector keep = a.view(0, 9).copy();
+        a = SubspaceMultiVector(basis, 1); // the 20-column store dies
+        basis->compress();
+        CHECK(basis->n_compress == 1 && basis->dim == 15);
+        CHECK(orthonormal(basis->P));
+        CHECK(same(keep.materialise(), HipMultiVectorWrapper(A0.view(0, 9)), 1e-13));
+        CHECK(same(b.materialise(), HipMultiVectorWrapper(B0.view(0, 4)), 1e-13));
+        // and the basis keeps working afterwards
+        SubspaceMultiVector more(basis, 3);
+        more.random();
+        CHECK(basis->dim == 18 && orthonormal(basis->P));
+    }
+}
+
 static void operator_cases(rails_ctx *ctx)
 {
     const int n = 10;
@@ -681,6 +738,7 @@ int main(int argc, char **argv)
             multivector_cases(st);
         }
         subspace_operator_cases(ctx);
+        subspace_basis_cases(ctx);
         rails_ctx_destroy(ctx);
     }
     std::printf("%s: %d checks, %d failures\n", host_only ? "host cases" : "all cases", g_checks, g_fail);
