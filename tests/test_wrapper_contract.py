@@ -9,13 +9,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "rails_amd", "lib", "wrapper_contract")
 
 
-def _run(args):
-    if not os.path.exists(EXE):
+def _run(args, exe=EXE, marker="ALL PASSED"):
+    if not os.path.exists(exe):
         import rails_amd.build
 
         rails_amd.build.build()
-    p = subprocess.run([EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-    assert p.returncode == 0 and "ALL PASSED" in p.stdout, p.stdout[-4000:]
+    p = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and marker in p.stdout, p.stdout[-4000:]
     return p.stdout
 
 
@@ -28,3 +28,10 @@ def test_dense_matrix_contract_on_host():
 def test_wrapper_contract_on_gpu():
     out = _run([])
     assert "all cases" in out
+
+
+@pytest.mark.gpu
+def test_cpp_example_program_solves_on_both_back_ends():
+    """examples/solve_laplace.cpp: a pure C++ host program on the header-only classes over the C ABI (no Python in the loop)"""
+    out = _run([], exe=os.path.join(ROOT, "rails_amd", "lib", "solve_laplace"), marker="OK")
+    assert "direct back end: return 0" in out and "coordinate-space back end: return 0" in out
