@@ -296,16 +296,16 @@ public:
             P2.set_global_rows(m_global);
         }
         P2.resize(rank);
-        Tick *rot = new Tick(this, &t_rotate);
-        for (int j0 = 0; j0 < rank; j0 += 128) { // 128 output columns per launch: the faster tile shape of k_panel_gemm
-            int nc = std::min(128, rank - j0);
-            if (!hip_ok(rails_panel_gemm(ctx, 1.0, P.panel(), 0, dim, Q.data() + (size_t)j0 * dim, dim, nc, 0.0, P2.panel(), j0), "rails_panel_gemm")) {
-                failed = true;
-                delete rot;
-                return;
+        {
+            Tick rot(this, &t_rotate);
+            for (int j0 = 0; j0 < rank; j0 += 128) { // 128 output columns per launch: the faster tile shape of k_panel_gemm
+                int nc = std::min(128, rank - j0);
+                if (!hip_ok(rails_panel_gemm(ctx, 1.0, P.panel(), 0, dim, Q.data() + (size_t)j0 * dim, dim, nc, 0.0, P2.panel(), j0), "rails_panel_gemm")) {
+                    failed = true;
+                    return;
+                }
             }
         }
-        delete rot;
         Tick tick(this, &t_recoef);
         // host: C <- Q' C (columns up to the last non-zero one of every store)
         for (auto &s : stores) {
