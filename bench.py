@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=14)
-    ap.add_argument("--m", type=int, default=1000000, help="rows per GPU")
+    ap.add_argument("--m", "--rows-per-gpu", dest="m", type=int, default=1000000, help="rows per GPU")
     ap.add_argument("--p", type=int, default=16, help="columns of B")
     ap.add_argument("--pattern", default="banded", choices=["banded", "stencil27", "uniform", "laplace7"])
     ap.add_argument("--bandwidth", type=int, default=4096)
@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=125000, help="rows of the bounded CPU sample")
     ap.add_argument("--spmm-variant", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend; gloo = rehearsal of the multi-process path "
+                    "(collectives staged through host memory, all ranks may share one GPU with --one-device)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box, at most 6 ranks)")
     ap.add_argument("--force-hooks", action="store_true", help="single rank: still route every reduction through torch.distributed (RCCL, world size 1)")
     ap.add_argument("--projected-lanczos", type=int, default=0, help="1: coefficient-space residual Lanczos (rails/HipSolverOps.hpp)")
     ap.add_argument("--subspace", type=int, default=1, help="1 (default): coordinate-space back end (rails/SubspaceWrappers.hpp); 0: direct panels")
@@ -121,7 +124,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
     nranks = world
@@ -135,7 +138,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29571")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     import rails_amd
     from rails_amd import partition
@@ -155,14 +161,15 @@ def main():
         starts = np.arange(nranks + 1, dtype=np.int64) * ml
         plan = partition.HaloPlan(starts, rank, colg, partition.all_gather_object_fn())
         A = rails_amd.HipOperatorWrapper(ctx, rowptr, plan.col_local, val, ncols_ext=ml + plan.n_ghost)
-        A.set_halo(plan, partition.make_halo(plan, on_device=True))
-        ctx.set_allreduce(partition.make_allreduce(on_device=True))
+        staged = args.backend != "nccl"
+        A.set_halo(plan, partition.make_halo(plan, on_device=True, host_staged=staged))
+        ctx.set_allreduce(partition.make_allreduce(on_device=True, host_staged=staged))
         halo_rows = plan.n_ghost
     else:
         A = rails_amd.HipOperatorWrapper(ctx, rowptr, colg.astype(np.int32), val)
         halo_rows = 0
         if args.force_hooks:
-            ctx.set_allreduce(partition.make_allreduce(on_device=True))
+            ctx.set_allreduce(partition.make_allreduce(on_device=True, host_staged=args.backend != "nccl"))
     A.set_variant(args.spmm_variant)
     nnz_local = int(rowptr[-1])
     log("[rank %d] setup %.1fs: %s, m_local=%d nnz=%d ghosts=%d" % (rank, time.time() - t_setup, desc, ml, nnz_local, halo_rows))
@@ -244,7 +251,7 @@ def main():
     assert solver.trips() == W + K, "solver stopped after %d trips (code %d)" % (solver.trips(), code)
     elapsed = marks[W + K] - marks[W]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     its = K / elapsed

@@ -78,25 +78,37 @@ def wrap_buffer(ptr, n, on_device):
     return torch.from_numpy(arr)
 
 
-def make_allreduce(on_device=True, group=None):
-    """pyfunc(dev_ptr, n, stream) for Context.set_allreduce / the oracle's hook."""
+def make_allreduce(on_device=True, group=None, host_staged=False):
+    """pyfunc(dev_ptr, n, stream) for Context.set_allreduce / the oracle's hook.  host_staged: device buffers travel through host
+    tensors (rehearsals of the multi-process path on a backend without device collectives, i.e. gloo)."""
     import torch.distributed as dist
 
     def allreduce(ptr, n, stream):
         t = wrap_buffer(ptr, n, on_device)
+        if on_device and host_staged:
+            h = t.cpu()  # synchronises with the current stream
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+            return 0
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return 0
 
     return allreduce
 
 
-def make_halo(plan, on_device=True, group=None):
+def make_halo(plan, on_device=True, group=None, host_staged=False):
     """pyfunc(send_ptr, recv_ptr, ncols, stream): exchange the packed rows with point-to-point messages."""
     import torch.distributed as dist
 
     def halo(send_ptr, recv_ptr, ncols, stream):
         send = wrap_buffer(send_ptr, plan.n_send * ncols, on_device)
         recv = wrap_buffer(recv_ptr, plan.n_ghost * ncols, on_device)
+        dev_recv = None
+        if on_device and host_staged:
+            import torch
+
+            send, dev_recv = send.cpu(), recv
+            recv = torch.empty(plan.n_ghost * ncols, dtype=torch.float64)
         ops = []
         so = ro = 0
         for r in range(plan.nranks):
@@ -111,6 +123,8 @@ def make_halo(plan, on_device=True, group=None):
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        if dev_recv is not None and plan.n_ghost:
+            dev_recv.copy_(recv)
         return 0
 
     return halo
