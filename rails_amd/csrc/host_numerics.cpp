@@ -25,6 +25,7 @@ namespace {
 extern "C" {
 typedef int (*lp_select2)(const double *, const double *);
 typedef void (*lp_dsyev)(const char *, const char *, const int *, double *, const int *, double *, double *, const int *, int *);
+typedef void (*lp_dsyevd)(const char *, const char *, const int *, double *, const int *, double *, double *, const int *, int *, const int *, int *);
 typedef void (*lp_dsteqr)(const char *, const int *, double *, double *, double *, const int *, double *, int *);
 typedef void (*lp_dgees)(const char *, const char *, lp_select2, const int *, double *, const int *, int *, double *, double *,
                          double *, const int *, double *, const int *, int *, int *);
@@ -44,6 +45,7 @@ struct HostLapack {
     void *handle = nullptr;
     std::string path;
     lp_dsyev dsyev = nullptr;
+    lp_dsyevd dsyevd = nullptr; // optional
     lp_dsteqr dsteqr = nullptr;
     lp_dgees dgees = nullptr;
     lp_dtrsyl dtrsyl = nullptr;
@@ -75,6 +77,7 @@ bool try_open(const std::string &path)
     L.handle = h;
     L.path = path;
     L.dsyev = (lp_dsyev)lookup(h, "dsyev_");
+    L.dsyevd = (lp_dsyevd)lookup(h, "dsyevd_");
     L.dsteqr = (lp_dsteqr)lookup(h, "dsteqr_");
     L.dgees = (lp_dgees)lookup(h, "dgees_");
     L.dtrsyl = (lp_dtrsyl)lookup(h, "dtrsyl_");
@@ -297,6 +300,69 @@ extern "C" void rails_sb03md(char dico, char job, char fact, char trans, int n, 
         return;
     }
     const bool tr = (trans == 'T' || trans == 't' || trans == 'C' || trans == 'c');
+    // Symmetric A (projections of symmetric operators: Laplacians, stencils): its Schur form is its eigen-decomposition
+    // A = Q L Q', and the triangular Sylvester solve collapses to Y_ij = F_ij / (l_i + l_j).  Same equation, same result up to
+    // rounding, about a third of the cost of dgees + dtrsyl.  Only for A symmetric to rounding; RAILS_SB03MD_SYMMETRIC=0 disables.
+    static const bool use_symmetric = [] {
+        const char *e = getenv("RAILS_SB03MD_SYMMETRIC");
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (use_symmetric && n >= 8) {
+        double amax = 0.0, asym = 0.0;
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < j; ++i) {
+                const double a = A[i + (size_t)j * lda], b = A[j + (size_t)i * lda];
+                amax = std::max(amax, std::max(std::fabs(a), std::fabs(b)));
+                asym = std::max(asym, std::fabs(a - b));
+            }
+        for (int i = 0; i < n; ++i) amax = std::max(amax, std::fabs(A[i + (size_t)i * lda]));
+        if (amax > 0.0 && asym <= 1e-13 * amax) {
+            std::vector<double> Q((size_t)n * n), lam(n), F((size_t)n * n), W((size_t)n * n);
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) Q[i + (size_t)j * n] = 0.5 * (A[i + (size_t)j * lda] + A[j + (size_t)i * lda]);
+            int sinfo = 0;
+            if (g_lp.dsyevd) {
+                int lwork = -1, liwork = -1, iq = 0;
+                double wq = 0.0;
+                g_lp.dsyevd("V", "U", &n, Q.data(), &n, lam.data(), &wq, &lwork, &iq, &liwork, &sinfo);
+                lwork = (int)wq + 1;
+                liwork = iq + 1;
+                std::vector<double> work((size_t)lwork);
+                std::vector<int> iwork((size_t)liwork);
+                g_lp.dsyevd("V", "U", &n, Q.data(), &n, lam.data(), work.data(), &lwork, iwork.data(), &liwork, &sinfo);
+            } else {
+                int lwork = 3 * n + 64;
+                std::vector<double> work((size_t)lwork);
+                g_lp.dsyev("V", "U", &n, Q.data(), &n, lam.data(), work.data(), &lwork, &sinfo);
+            }
+            if (sinfo == 0) {
+                gemm('T', 'N', n, n, n, Q.data(), n, X, ldx, W.data(), n);
+                gemm('N', 'N', n, n, n, W.data(), n, Q.data(), n, F.data(), n);
+                bool singular = false;
+                for (int j = 0; j < n && !singular; ++j)
+                    for (int i = 0; i < n; ++i) {
+                        const double den = lam[i] + lam[j];
+                        if (!(std::fabs(den) > 1e-300)) {
+                            singular = true;
+                            break;
+                        }
+                        F[i + (size_t)j * n] /= den;
+                    }
+                if (!singular) {
+                    gemm('N', 'N', n, n, n, Q.data(), n, F.data(), n, W.data(), n);
+                    gemm('N', 'T', n, n, n, W.data(), n, Q.data(), n, F.data(), n);
+                    for (int j = 0; j < n; ++j)
+                        for (int i = 0; i < n; ++i) {
+                            X[i + (size_t)j * ldx] = F[i + (size_t)j * n];
+                            A[i + (size_t)j * lda] = (i == j) ? lam[i] : 0.0; // the (diagonal) Schur form, as the general path leaves it
+                        }
+                    *scale = 1.0;
+                    return;
+                }
+            }
+            // eigen-solver trouble or lambda_i + lambda_j = 0: let the general path deal with it
+        }
+    }
     std::vector<double> U((size_t)n * n), wr(n), wi(n), F((size_t)n * n), W((size_t)n * n);
     int sdim = 0, lwork = -1, linfo = 0;
     double wq = 0.0;
