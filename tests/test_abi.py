@@ -80,6 +80,32 @@ def test_host_sb03md_matches_oracle(oracle):
         assert inf.value == 0
         np.testing.assert_allclose(Xp, Xo, atol=1e-12)
         assert np.abs(A @ Xp + Xp @ A.T - scale.value * Cm).max() < 1e-12
+    # symmetric A takes the eigen-decomposition path (and n >= 64 the blocked triangular solver on the general path): the same
+    # equation, checked against the oracle's Bartels-Stewart solve and by its residual, for both values of trans
+    for n in (9, 40, 130):
+        S = g.uniform(-1, 1, (n, n))
+        A = -(S @ S.T) / n - np.eye(n)
+        Cm = g.uniform(-1, 1, (n, n))
+        Cm = Cm + Cm.T
+        Xo, sc, info = oracle.sb03md(A, Cm)
+        for trans in (b"T", b"N"):
+            Ap, Xp = np.asfortranarray(A.copy()), np.asfortranarray(Cm.copy())
+            scale, inf = C.c_double(1.0), C.c_int(0)
+            lib.rails_sb03md(b"C", b"X", b"N", trans, n, Ap.ctypes.data_as(dp), n, Xp.ctypes.data_as(dp), n, C.byref(scale), C.byref(inf))
+            assert inf.value == 0 and scale.value == 1.0
+            np.testing.assert_allclose(Xp, Xo, atol=1e-11)
+            assert np.abs(A @ Xp + Xp @ A.T - Cm).max() < 1e-11
+            assert np.abs(Ap - np.diag(np.diag(Ap))).max() == 0.0  # A comes back as its (diagonal) Schur form
+    n = 130
+    A = g.uniform(-1, 1, (n, n)) - 6 * np.eye(n)
+    Cm = g.uniform(-1, 1, (n, n))
+    Cm = Cm + Cm.T
+    Xo, sc, info = oracle.sb03md(A, Cm)
+    Ap, Xp = np.asfortranarray(A.copy()), np.asfortranarray(Cm.copy())
+    scale, inf = C.c_double(1.0), C.c_int(0)
+    lib.rails_sb03md(b"C", b"X", b"N", b"T", n, Ap.ctypes.data_as(dp), n, Xp.ctypes.data_as(dp), n, C.byref(scale), C.byref(inf))
+    assert inf.value == 0
+    np.testing.assert_allclose(Xp * sc / scale.value, Xo, atol=1e-11)
 
 
 def test_host_dsyev_and_dsteqr():
