@@ -55,10 +55,6 @@ public:
     std::vector<std::weak_ptr<CoefStore>> live;
     long n_absorb = 0, n_absorb_cols = 0, n_single = 0, n_compress = 0, n_materialise = 0, n_dropped = 0, n_prefetched = 0;
     bool failed = false;
-    // The next 1-column random() of the solver (the Lanczos start vector of the coming trip, src/LyapunovSolver.hpp:374) is
-    // drawn ahead of time and expressed in the basis together with the A*W block it follows: one more column in a block
-    // projection instead of two passes over the basis of its own.  The RNG stream it consumes is the one that random() call
-    // would have consumed (streams are handed out in call order and nothing else draws in between).
     // wall-clock split (seconds); with RAILS_SUBSPACE_PROFILE=1 the device is synchronised around every part so that the numbers
     // are those of the part itself
     double t_materialise = 0, t_absorb = 0, t_qr = 0, t_rotate = 0, t_recoef = 0;
@@ -78,6 +74,10 @@ public:
             *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
     };
+    // The next 1-column random() of the solver (the Lanczos start vector of the coming trip, src/LyapunovSolver.hpp:374) is
+    // drawn ahead of time and expressed in the basis together with the A*W block it follows: one more column in a block
+    // projection instead of two passes over the basis of its own.  The RNG stream it consumes is the one that random() call
+    // would have consumed (streams are handed out in call order and nothing else draws in between).
     std::shared_ptr<CoefStore> cached_random;
     bool cached_valid = false;
     bool prefetch_random = true;
