@@ -53,7 +53,7 @@ public:
     int dim = 0;
     int row_cap; // leading dimension of every coefficient store
     std::vector<std::weak_ptr<CoefStore>> live;
-    long n_absorb = 0, n_absorb_cols = 0, n_single = 0, n_compress = 0, n_materialise = 0, n_dropped = 0, n_prefetched = 0;
+    long n_absorb = 0, n_absorb_cols = 0, n_single = 0, n_compress = 0, n_materialise = 0, n_dropped = 0, n_prefetched = 0, n_second_round = 0;
     bool failed = false;
     // wall-clock split (seconds); with RAILS_SUBSPACE_PROFILE=1 the device is synchronised around every part so that the numbers
     // are those of the part itself
@@ -188,6 +188,7 @@ public:
                 // "twice is enough": the second projection repairs the orthogonality lost to cancellation in the first one (a
                 // relative eps * ||x|| / ||x - P P'x||); where more than a hundredth of every column survives there is nothing to repair
                 if (worst > 0.01) break;
+                n_second_round++;
             } else {
                 // after the second round the block's Gram matrix is the one just measured minus the (tiny) second correction
                 for (int j = 0; j < w; ++j)
