@@ -303,7 +303,8 @@ def main():
             "config": {"workload": "BASELINE configs[2]: m=%d rows/GPU (global %d), 27 nnz/row %s CSR, B m x %d, Restart size %d, Reduced size %d, "
                                    "Expand size %d, Lanczos iterations %d" % (ml, mg, desc, args.p, args.restart, args.reduced, args.expand, args.lanczos),
                        "parallelism": "row-partition x%d, RCCL all-reduce of projected blocks" % nranks if nranks > 1 else "single GPU",
-                       "spmm_columns": kk, "residual_lanczos": "projected" if args.projected_lanczos else "fused",
+                       "spmm_columns": kk, "residual_lanczos": ("the reference's recurrence on coordinate vectors (host)" if args.subspace else
+                                            ("coefficient-space, Gram differences" if args.projected_lanczos else "fused one-pass-per-step kernel")),
                        "backend": "coordinates in a device-resident orthonormal basis" if args.subspace else "direct panels"},
             "roofline": {"bound": "hbm", "kernel": spmm_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms},
