@@ -810,15 +810,20 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_reg(int64_t m, int64_t ntile
     // Two column chunks are in flight in registers per thread (Little's law: with one chunk in flight the kernel is bound
     // by bytes-in-flight x latency, ~41 KB per CU); chunk ci goes to LDS buffer (ci & 1) right before use and its
     // register set is refilled with chunk ci + 2.  Loads past the last chunk are clamped to it (unused).
-    double2_t stage0[NL], stage1[NL];
+    double2_t stage0[NL], stage1[NL], stage2[NL];
     const int nchunks = (nc + KC - 1) / KC;
     const int lastc = (nchunks - 1) * KC;
 #pragma unroll
     for (int i = 0; i < NL; ++i) stage0[i] = *reinterpret_cast<const double2_t *>(RAILS_SRC(i));
-    if (NS == 2) {
+    if (NS >= 2) {
         const int c1 = KC < lastc ? KC : lastc;
 #pragma unroll
         for (int i = 0; i < NL; ++i) stage1[i] = *reinterpret_cast<const double2_t *>(RAILS_SRC(i) + c1);
+    }
+    if (NS >= 3) {
+        const int c2 = 2 * KC < lastc ? 2 * KC : lastc;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) stage2[i] = *reinterpret_cast<const double2_t *>(RAILS_SRC(i) + c2);
     }
 #define RAILS_TILE_STEP(STAGE, CI)                                                                      \
     do {                                                                                                \
@@ -853,7 +858,13 @@ __global__ __launch_bounds__(256) void k_spmm_tiled_reg(int64_t m, int64_t ntile
             }                                                                                           \
         }                                                                                               \
     } while (0)
-    if (NS == 2) {
+    if (NS == 3) {
+        for (int ci = 0; ci < nchunks; ci += 3) {
+            RAILS_TILE_STEP(stage0, ci);
+            if (ci + 1 < nchunks) RAILS_TILE_STEP(stage1, ci + 1);
+            if (ci + 2 < nchunks) RAILS_TILE_STEP(stage2, ci + 2);
+        }
+    } else if (NS == 2) {
         for (int ci = 0; ci < nchunks; ci += 2) {
             RAILS_TILE_STEP(stage0, ci);
             if (ci + 1 < nchunks) RAILS_TILE_STEP(stage1, ci + 1);
@@ -1170,13 +1181,24 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
         const size_t lds_reg = 2 * (size_t)xs_r * 8;
         if (env_reg && (wide || full_width_ok) && xs_r < 65536 && (int64_t)A->m * ldx < 0x7fffffffLL && (int64_t)(A->n_ghost + 1) * ldg < 0x7fffffffLL && A->tile_rows <= 256 / lpr_r && A->max_row_nnz <= 32 && need_nl_r <= 8 && lds_reg <= (size_t)lds_budget) {
             const int nnz4 = (A->max_row_nnz + 3) / 4;
+            // chunks in flight in registers for long rows: 2 = deeper pipeline at 2 waves/SIMD, 1 = 16 fewer VGPRs, 3 waves/SIMD
+            static const int env_ns = spmm_env("RAILS_SPMM_TILE_NS", 2);
 #define RAILS_REG_ARGS A->m, A->n_tiles, A->t_rowptr, A->t_rows, A->t_nzptr, A->t_rp, A->t_val, A->t_lcol, A->t_fp_ptr, A->t_fp, A->t_fpos, X, ldx, Xg, ldg, Y, ldy, nc, tpx, xs_r
 // two chunks in flight unless that needs more than 256 VGPRs (wide chunks with long rows and 8 staging slots)
-#define RAILS_LAUNCH_REG(KCV, NNZV, NLV, V2V)                                                                                         \
+#define RAILS_LAUNCH_REG_NS(KCV, NNZV, NLV, V2V, NSV)                                                                                 \
     do {                                                                                                                               \
-        constexpr int NSV = (V2V == 2 && NNZV * 2 + NLV * 8 > 100) ? 1 : 2;                                                           \
         RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled_reg<KCV, NNZV, NLV, V2V, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg)); \
         hipLaunchKernelGGL((k_spmm_tiled_reg<KCV, NNZV, NLV, V2V, NSV>), dim3((unsigned)grid), dim3(256), lds_reg, c->stream, RAILS_REG_ARGS); \
+    } while (0)
+#define RAILS_LAUNCH_REG(KCV, NNZV, NLV, V2V)                                                                                         \
+    do {                                                                                                                               \
+        constexpr bool tight = (V2V == 2 && NNZV * 2 + NLV * 8 > 100);                                                                 \
+        if (tight || (env_ns == 1 && NNZV > 16))                                                                                       \
+            RAILS_LAUNCH_REG_NS(KCV, NNZV, NLV, V2V, 1);                                                                               \
+        else if (env_ns == 3 && V2V == 1 && NLV == 4)                                                                                  \
+            RAILS_LAUNCH_REG_NS(KCV, NNZV, NLV, V2V, 3);                                                                               \
+        else                                                                                                                           \
+            RAILS_LAUNCH_REG_NS(KCV, NNZV, NLV, V2V, 2);                                                                               \
     } while (0)
 #define RAILS_REG_NL(KCV, NNZV, V2V)                             \
     do {                                                         \
@@ -1199,6 +1221,7 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
 #undef RAILS_REG_NNZ
 #undef RAILS_REG_NL
 #undef RAILS_LAUNCH_REG
+#undef RAILS_LAUNCH_REG_NS
 #undef RAILS_REG_ARGS
             A->last_kernel = "k_spmm_tiled_reg";
             *done = true;
