@@ -40,3 +40,25 @@ def test_two_ranks_share_one_gpu():
     # rank's row block from its own seed, so there is no single-process twin of this run)
     last = [float(m.group(1)) for m in re.finditer(r"Lanczos estimates [0-9.e+-]+ -> ([0-9.e+-]+);", err2)]
     assert len(last) == 2 and last[0] == last[1] and last[0] < 1e-3 * first2[0]  # and the iteration converges
+
+
+def test_bench_line_contract():
+    """the one JSON line of `python bench.py` (N = 1, small sizes): every field the bench contract names, with sane values"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rows-per-gpu", "60000", "--steps", "5", "--warmup", "3", "--spmm-reps", "2", "--cpu-rows", "8000"]
+    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 3 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and d["unit"] == "iterations/s"
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert "traffic" in r and r["achieved"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iterations/s" and "sample" in c
