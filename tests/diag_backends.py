@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: residual-estimate history of the fused and of the projected residual Lanczos against the CPU oracle, trip by trip."""
+"""Diagnostic (lives under tests/ because it uses the CPU oracle, which only test code may touch): residual-estimate history of the
+direct back end, its coefficient-space Lanczos and the coordinate-space back end against the oracle, trip by trip.
+    python tests/diag_backends.py        (on the GPU box)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
