@@ -227,7 +227,7 @@ template <int LPR>
 int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc)
 {
     constexpr int GROUPS = 256 / LPR;
-    constexpr int RPG = (LPR >= 32) ? 8 : 4;
+    constexpr int RPG = (LPR >= 32) ? 8 : (LPR >= 16 ? 4 : 2);
     constexpr int ROWS = GROUPS * RPG; // 64 rows per block
     constexpr int CC = 2 * LPR;
     const int nchunks = (nc + CC - 1) / CC;
@@ -473,8 +473,17 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     if (done) c->n_spmm_tiled++;
     if (!done) {
         RAILS_REQUIRE(A->variant != 2 && A->variant != 6, "rails_spmm: LDS-staged kernel requested but not applicable to this operator/shape");
-        const int cc = vec2 ? rowgather_chunk(A, nc) : 0;
-        if (cc == 32)
+        int cc = vec2 ? rowgather_chunk(A, nc) : 0;
+        // narrow panels (the in-loop A*W at Expand size <= 16): the same kernel with one chunk -- (col, val) of a 64-row block staged
+        // in LDS instead of per-lane vector-memory loads: 0.38 vs 0.45 ms at 16 columns (banded), 0.37 vs 0.42 (stencil); at 32
+        // columns the two forms tie, so that stays with the plain kernel (RAILS_SPMM_NARROW_CC=0 disables, =2 also takes 32)
+        static const int narrow_env = spmm_env("RAILS_SPMM_NARROW_CC", 1);
+        if (cc == 0 && vec2 && narrow_env && A->variant != 3 && nc > 8 && nc <= (narrow_env == 2 ? 32 : 16) && A->max_row_nnz <= 64) cc = nc <= 16 ? 16 : -32;
+        if (cc == 16)
+            RAILS_TRY((launch_rg_cc<8>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
+        else if (cc == -32)
+            RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
+        else if (cc == 32)
             RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
         else if (cc == 64)
             RAILS_TRY((launch_rg_cc<32>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
