@@ -100,6 +100,12 @@ typedef int (*rails_halo_fn)(void *user, const double *send_buf, double *recv_bu
  * Epetra_OperatorWrapper.cpp:75-91; StlWrapper.cpp:168-187 for the dense Stl form). */
 int rails_csr_create(rails_ctx *ctx, int64_t m_local, int64_t n_cols_ext, const int64_t *rowptr,
                      const int32_t *col, const double *val, rails_csr **out);
+/* An operator given by its action instead of a CSR block (composite operators such as the reference's Schur complement
+ * A22 - A21 A11^-1 A12, src/SchurOperator.cpp:181-214; matrix-free operators): rails_spmm on the returned handle calls
+ * fn(user, trans, X, xc0, nc, Y, yc0), which must set Y[:, yc0:yc0+nc] = op(A) X[:, xc0:xc0+nc] with the C-ABI panel functions on
+ * the context's stream and return 0.  The handle takes the Matrix role everywhere a CSR handle does (single GPU). */
+typedef int (*rails_apply_fn)(void *user, int trans, const rails_panel *X, int xc0, int nc, rails_panel *Y, int yc0);
+int rails_csr_create_callback(rails_ctx *ctx, int64_t m_local, rails_apply_fn fn, void *user, rails_csr **out);
 int rails_csr_destroy(rails_csr *A);
 int64_t rails_csr_rows(const rails_csr *A);
 int64_t rails_csr_nnz(const rails_csr *A);

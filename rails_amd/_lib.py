@@ -18,6 +18,7 @@ _vp = C.c_void_p
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int)
 
 # name -> (restype, argtypes); every symbol include/rails_hip.h declares
 SIGNATURES = {
@@ -33,6 +34,7 @@ SIGNATURES = {
     "rails_ctx_set_partition": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int64, C.c_int64]),
     "rails_ctx_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
     "rails_csr_create": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, _i32p, _dp, C.POINTER(_vp)]),
+    "rails_csr_create_callback": (C.c_int, [_vp, C.c_int64, APPLY_FN, _vp, C.POINTER(_vp)]),
     "rails_csr_destroy": (C.c_int, [_vp]),
     "rails_csr_rows": (C.c_int64, [_vp]),
     "rails_csr_nnz": (C.c_int64, [_vp]),

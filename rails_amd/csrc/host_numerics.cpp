@@ -147,6 +147,15 @@ extern "C" int rails_host_lapack_init(const char *path)
 
 extern "C" const char *rails_host_lapack_path(void) { return g_lp.path.c_str(); }
 
+// LAPACK's eigen-solvers may not return (or may index out of bounds) on NaN / Inf input: refuse it with an error code instead.
+static bool all_finite(int rows, int cols, const double *a, int lda)
+{
+    for (int j = 0; j < cols; ++j)
+        for (int i = 0; i < rows; ++i)
+            if (!std::isfinite(a[i + (size_t)j * lda])) return false;
+    return true;
+}
+
 extern "C" void rails_dsyev(char jobz, char uplo, int n, double *a, int lda, double *w, int *info)
 {
     if (rails_host_lapack_init(nullptr) != RAILS_OK) {
@@ -155,6 +164,11 @@ extern "C" void rails_dsyev(char jobz, char uplo, int n, double *a, int lda, dou
     }
     if (n <= 0) {
         *info = 0;
+        return;
+    }
+    if (!all_finite(n, n, a, lda)) {
+        fprintf(stderr, "rails_dsyev: the matrix holds NaN or Inf entries\n");
+        *info = n + 1;
         return;
     }
     if (g_lp.dsyevd && n >= 64 && (jobz == 'V' || jobz == 'v')) { // divide and conquer: 2-3x faster at the restart sizes (eig(T), k = 200)
@@ -310,6 +324,11 @@ extern "C" void rails_sb03md(char dico, char job, char fact, char trans, int n, 
     }
     if (rails_host_lapack_init(nullptr) != RAILS_OK) {
         *info = -100;
+        return;
+    }
+    if (!all_finite(n, n, A, lda) || !all_finite(n, n, X, ldx)) {
+        fprintf(stderr, "rails_sb03md: A or C holds NaN or Inf entries\n");
+        *info = n + 2;
         return;
     }
     const bool tr = (trans == 'T' || trans == 't' || trans == 'C' || trans == 'c');

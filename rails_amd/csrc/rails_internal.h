@@ -121,6 +121,9 @@ struct rails_csr {
     double tile_reuse = 0.0;
     bool tile_grid = false;
     const char *last_kernel = "";
+    // operator given by its action (rails_csr_create_callback): rails_spmm hands the panels over
+    rails_apply_fn apply_cb = nullptr;
+    void *apply_user = nullptr;
 };
 
 // ---- helpers implemented in ctx.hip ----

@@ -351,6 +351,20 @@ extern "C" int rails_csr_create(rails_ctx *c, int64_t m_local, int64_t n_cols_ex
     return RAILS_OK;
 }
 
+extern "C" int rails_csr_create_callback(rails_ctx *c, int64_t m_local, rails_apply_fn fn, void *user, rails_csr **out)
+{
+    RAILS_REQUIRE(c && out && fn && m_local >= 0, "rails_csr_create_callback: bad argument");
+    rails_csr *A = new rails_csr();
+    A->ctx = c;
+    A->m = m_local;
+    A->ncols_ext = m_local;
+    A->apply_cb = fn;
+    A->apply_user = user;
+    A->last_kernel = "callback";
+    *out = A;
+    return RAILS_OK;
+}
+
 extern "C" int rails_csr_destroy(rails_csr *A)
 {
     if (!A) return RAILS_OK;
@@ -425,6 +439,14 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
                   (long long)Y->m);
     if (X->d == Y->d) RAILS_REQUIRE(xc0 + nc <= yc0 || yc0 + nc <= xc0, "rails_spmm: X and Y windows alias");
     if (nc == 0 || A->m == 0) return RAILS_OK;
+    if (A->apply_cb) {
+        int rc = A->apply_cb(A->apply_user, trans ? 1 : 0, X, xc0, nc, Y, yc0);
+        if (rc != 0) {
+            rails_set_error("rails_spmm: the operator callback failed with code %d", rc);
+            return RAILS_ECOMM;
+        }
+        return RAILS_OK;
+    }
     if (trans) {
         RAILS_TRY(build_transpose(A));
         A->AT->variant = A->variant;

@@ -53,7 +53,7 @@ public:
     int dim = 0;
     int row_cap; // leading dimension of every coefficient store
     std::vector<std::weak_ptr<CoefStore>> live;
-    long n_absorb = 0, n_absorb_cols = 0, n_single = 0, n_compress = 0, n_materialise = 0, n_dropped = 0, n_prefetched = 0, n_second_round = 0;
+    long n_absorb = 0, n_absorb_cols = 0, n_single = 0, n_compress = 0, n_materialise = 0, n_dropped = 0, n_prefetched = 0, n_second_round = 0, n_delicate = 0, n_reprojected = 0;
     bool failed = false;
     // wall-clock split (seconds); with RAILS_SUBSPACE_PROFILE=1 the device is synchronised around every part so that the numbers
     // are those of the part itself
@@ -209,6 +209,33 @@ public:
             else
                 n_dropped++;
         }
+        // A column of which less than 1e-4 of its length survived the projections may be nothing but their rounding error --
+        // normalised, such a "direction" would not be orthogonal to P (error ~ eps / survival) and poison the basis; this happens
+        // when span(P) is (nearly) the whole space or the block repeats old vectors.  Test: normalise the survivors and project
+        // once more; a genuine direction keeps most of its unit length, rounding noise does not.
+        std::vector<double> colscale(w, 1.0); // original residual column = colscale * column now in the panel
+        bool delicate = false;
+        for (int j : keep)
+            if (G[j + (size_t)j * w] < 1e-8 * G0[j + (size_t)j * w]) delicate = true;
+        if (delicate && dim > 0) {
+            n_delicate++;
+            for (int j : keep) {
+                colscale[j] = std::sqrt(G[j + (size_t)j * w]);
+                if (!hip_ok(rails_panel_scale(ctx, pp, dim + j, 1, 1.0 / colscale[j]), "rails_panel_scale")) return fail();
+            }
+            if (!hip_ok(rails_gram(ctx, pp, 0, dim, pp, dim, w, CG.data(), dim), "rails_gram")) return fail();
+            if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, CG.data(), dim, w, 1.0, pp, dim), "rails_panel_gemm")) return fail();
+            if (!hip_ok(rails_gram(ctx, pp, dim, w, pp, dim, w, G.data(), w), "rails_gram")) return fail();
+            std::vector<int> survivors;
+            for (int j : keep) {
+                if (G[j + (size_t)j * w] > 0.25) {
+                    for (int i = 0; i < dim; ++i) coef[i + (size_t)j * ld] += colscale[j] * CG[i + (size_t)j * dim];
+                    survivors.push_back(j);
+                } else
+                    n_dropped++;
+            }
+            keep.swap(survivors);
+        }
         const int r = (int)keep.size();
         if (r == 0) return true;
         // Cholesky of the diagonally scaled Gram matrix of the kept columns
@@ -222,7 +249,7 @@ public:
         bool ok = info == 0;
         for (int a = 0; a < r && ok; ++a)
             if (!(R1[a + (size_t)a * r] > 1e-6)) ok = false;
-        if (!ok) return absorb_one_by_one(w, coef, keep);
+        if (!ok) return absorb_one_by_one(w, coef, keep, colscale);
         for (int b = 0; b < r; ++b)
             for (int a = b + 1; a < r; ++a) R1[a + (size_t)b * r] = 0.0;
         // Q1 = X[:, keep] D^-1 R1^-1, written over the whole tail block in place (dropped columns become zero, Q1 fills the
@@ -244,12 +271,29 @@ public:
         upper_inverse(R2, r, R2inv);
         if (!hip_ok(rails_panel_gemm(ctx, 1.0, pp, dim, r, R2inv.data(), r, r, 0.0, pp, dim), "rails_panel_gemm")) return fail();
         // X[:, keep[b]] = Q * (R2 * R1(:, b)) * d[b]
+        std::vector<double> Rf((size_t)r * r, 0.0);
         for (int b = 0; b < r; ++b)
-            for (int a = 0; a < r; ++a) {
+            for (int a = 0; a <= b; ++a) {
                 double s = 0.0;
                 for (int l = a; l <= b; ++l) s += R2[a + (size_t)l * r] * R1[l + (size_t)b * r];
-                coef[(dim + a) + (size_t)keep[b] * ld] = s * d[b];
+                Rf[a + (size_t)b * r] = s * d[b] * colscale[keep[b]];
+                coef[(dim + a) + (size_t)keep[b] * ld] = Rf[a + (size_t)b * r];
             }
+        // An ill-conditioned block: Q = X R^-1 has magnified what rounding left of span(P) in X by up to 1 / min diag(R1).  Take
+        // it out again (it is tiny: the block stays orthonormal to second order) and book it on the old coordinates.
+        double rmin = 1.0;
+        for (int a = 0; a < r; ++a) rmin = std::min(rmin, R1[a + (size_t)a * r]);
+        if (rmin < 1e-2 && dim > 0) {
+            n_reprojected++;
+            std::vector<double> C3((size_t)dim * r);
+            if (!hip_ok(rails_gram(ctx, pp, 0, dim, pp, dim, r, C3.data(), dim), "rails_gram")) return fail();
+            if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, C3.data(), dim, r, 1.0, pp, dim), "rails_panel_gemm")) return fail();
+            for (int b = 0; b < r; ++b)
+                for (int l = 0; l <= b; ++l) {
+                    const double f = Rf[l + (size_t)b * r];
+                    for (int i = 0; i < dim; ++i) coef[i + (size_t)keep[b] * ld] += C3[i + (size_t)l * dim] * f;
+                }
+        }
         dim += r;
         P.resize(dim);
         return true;
@@ -355,7 +399,7 @@ private:
     // degenerate block (its kept columns are dependent among themselves after the projection): take the columns one at a
     // time, each against the basis extended by its predecessors.  The tail block holds the twice-projected columns; coef holds
     // their coordinates in the old basis.
-    bool absorb_one_by_one(int w, double *coef, std::vector<int> const &keep)
+    bool absorb_one_by_one(int w, double *coef, std::vector<int> const &keep, std::vector<double> const &colscale)
     {
         n_single++;
         const int ld = row_cap;
@@ -373,7 +417,7 @@ private:
                 std::vector<double> c(accepted);
                 if (!hip_ok(rails_gram(ctx, pp, base, accepted, pp, dst, 1, c.data(), accepted), "rails_gram")) return fail();
                 if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, base, accepted, c.data(), accepted, 1, 1.0, pp, dst), "rails_panel_gemm")) return fail();
-                for (int a = 0; a < accepted; ++a) coef[(base + a) + (size_t)j * ld] += c[a];
+                for (int a = 0; a < accepted; ++a) coef[(base + a) + (size_t)j * ld] += colscale[j] * c[a];
             }
             if (!hip_ok(rails_gram(ctx, pp, dst, 1, pp, dst, 1, &g, 1), "rails_gram")) return fail();
             if (!(g > 1e-24 * g0) || !(g > 0.0)) {
@@ -382,7 +426,25 @@ private:
             }
             const double nrm = std::sqrt(g);
             if (!hip_ok(rails_panel_scale(ctx, pp, dst, 1, 1.0 / nrm), "rails_panel_scale")) return fail();
-            coef[(base + accepted) + (size_t)j * ld] = nrm;
+            double last = nrm;
+            if (g < 1e-8 * g0 && base + accepted > 0) {
+                // less than 1e-4 of the column was left: is it a direction or the rounding error of the projections?  Project the
+                // normalised vector against the whole basis so far; a direction survives (and is now orthogonal to rounding)
+                const int nb = base + accepted;
+                std::vector<double> c(nb);
+                double n2 = 0.0;
+                if (!hip_ok(rails_gram(ctx, pp, 0, nb, pp, dst, 1, c.data(), nb), "rails_gram")) return fail();
+                if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, nb, c.data(), nb, 1, 1.0, pp, dst), "rails_panel_gemm")) return fail();
+                if (!hip_ok(rails_gram(ctx, pp, dst, 1, pp, dst, 1, &n2, 1), "rails_gram")) return fail();
+                if (!(n2 > 0.25)) {
+                    n_dropped++;
+                    continue;
+                }
+                for (int a = 0; a < nb; ++a) coef[a + (size_t)j * ld] += colscale[j] * nrm * c[a];
+                if (!hip_ok(rails_panel_scale(ctx, pp, dst, 1, 1.0 / std::sqrt(n2)), "rails_panel_scale")) return fail();
+                last = nrm * std::sqrt(n2);
+            }
+            coef[(base + accepted) + (size_t)j * ld] = colscale[j] * last;
             accepted++;
         }
         dim = base + accepted;

@@ -1,0 +1,70 @@
+"""Schur-complement operator for descriptor systems with a singular diagonal mass matrix.
+
+The reference builds it with Trilinos (src/SchurOperator.cpp:51-214): rows / columns are split into the set 1 where the mass
+matrix is zero (algebraic constraints) and the set 2 where it is not; the operator the Lyapunov solver sees is
+
+    S = A22 - A21 * A11^-1 * A12                                                   (src/SchurOperator.cpp:181-214)
+
+with a sparse LU factorisation of A11 (Amesos KLU there, SuperLU through scipy here, on the host like the reference's serial KLU).
+Here `S * X`: A22 * X is the CSR SpMM kernel on the device; the correction A21 (A11 \\ (A12 X)) goes through the host (download
+X, two sparse products and the LU solves, upload) and is subtracted on the device.  The operator plugs into the solver through
+the C ABI's operator-callback handle (rails_csr_create_callback), so both back ends of the solver template run on it unchanged.
+Single rank, like the reference ("TODO: Fix these maps to work in parallel runs", src/SchurOperator.cpp:226).
+"""
+import numpy as np
+
+from ._lib import check
+from .wrappers import HipMultiVectorWrapper, HipOperatorWrapper
+
+
+class SchurOperator:
+    def __init__(self, ctx, A, mass_diagonal, tol=1e-15):
+        """A: (rowptr, col, val) CSR of the full n x n operator; mass_diagonal: the n diagonal entries of M."""
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+
+        rowptr, col, val = A
+        n = rowptr.size - 1
+        d = np.asarray(mass_diagonal, dtype=np.float64)
+        assert d.shape == (n,)
+        self.idx1 = np.flatnonzero(np.abs(d) < tol)   # M_ii = 0 (src/SchurOperator.cpp:70-76)
+        self.idx2 = np.flatnonzero(np.abs(d) >= tol)
+        self.m1, self.m2 = self.idx1.size, self.idx2.size
+        if self.m1 == 0:
+            raise ValueError("the mass matrix is nonsingular: no Schur complement to take")
+        As = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+        self.A11 = As[self.idx1][:, self.idx1].tocsc()
+        self.A12 = As[self.idx1][:, self.idx2].tocsr()
+        self.A21 = As[self.idx2][:, self.idx1].tocsr()
+        A22 = As[self.idx2][:, self.idx2].tocsr()
+        A22.sort_indices()
+        self.lu = spla.splu(self.A11)  # symbolic + numeric factorisation (src/SchurOperator.cpp:171-176)
+        self.mass22 = d[self.idx2].copy()
+        self.ctx = ctx
+        self.A22 = HipOperatorWrapper(ctx, A22.indptr.astype(np.int64), A22.indices.astype(np.int32), A22.data.astype(np.float64))
+        self.applies = 0  # matrix-vector products, as SchurOperator::GetMVPs counts them
+        self.op = HipOperatorWrapper.from_callback(ctx, self.m2, self._apply)
+
+    def _apply(self, trans, X, Y):
+        """Y = S X (or S' X): device SpMM with A22, host correction through the LU factors of A11"""
+        self.applies += X.n
+        lib = self.ctx.lib
+        check(lib.rails_spmm(self.ctx.h, self.A22.h.h, 1 if trans else 0, X.panel.h, X.c0, X.n, Y.panel.h, Y.c0), "rails_spmm")
+        Xh = X.to_host()
+        if not trans:
+            corr = self.A21 @ self.lu.solve(np.ascontiguousarray(self.A12 @ Xh))
+        else:  # S' = A22' - A12' A11^-T A21'
+            corr = self.A12.T @ self.lu.solve(np.ascontiguousarray(self.A21.T @ Xh), trans="T")
+        tmp = HipMultiVectorWrapper(self.ctx, data=np.asfortranarray(corr.reshape(self.m2, X.n)))
+        check(lib.rails_panel_axpy(self.ctx.h, -1.0, tmp.panel.h, 0, X.n, Y.panel.h, Y.c0), "rails_panel_axpy")
+        self.ctx.sync()  # tmp is released when this returns
+        return 0
+
+    def restrict(self, B):
+        """rows of B on the set-2 unknowns (the reference imports B into the Schur operator's range map, src/main.cpp:83-88)"""
+        return np.asfortranarray(np.asarray(B)[self.idx2])
+
+    def dense(self):
+        """the Schur complement as a dense matrix (tests, small problems)"""
+        A22 = self.A22.apply(HipMultiVectorWrapper(self.ctx, data=np.eye(self.m2))).to_host()
+        return A22 - self.A21 @ self.lu.solve(self.A12.toarray())

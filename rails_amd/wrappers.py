@@ -119,6 +119,17 @@ class _Panel:
             pass
 
 
+class _BorrowedPanel:
+    """a panel handle owned by the library (or by another object): same attributes as _Panel, no destructor"""
+
+    def __init__(self, ctx, h, m):
+        self.ctx, self.h, self.m = ctx, C.c_void_p(h) if not isinstance(h, C.c_void_p) else h, m
+
+    @property
+    def capacity(self):
+        return self.ctx.lib.rails_panel_capacity(self.h)
+
+
 class HipMultiVectorWrapper:
     """Row-partitioned device multivector: a column window [c0, c0+n) of a shared panel."""
 
@@ -135,6 +146,15 @@ class HipMultiVectorWrapper:
         self.orthogonalized = 0
         if data is not None and n:
             check(ctx.lib.rails_panel_upload(ctx.h, self.panel.h, 0, n, _p(data), data.shape[0]), "rails_panel_upload")
+
+    @classmethod
+    def _borrow(cls, ctx, panel_ptr, c0, n, m):
+        """a view onto a panel the library owns (operator callbacks): nothing is freed when it goes away"""
+        v = cls.__new__(cls)
+        v.ctx = ctx
+        v.panel = _BorrowedPanel(ctx, panel_ptr, m)
+        v.c0, v.n, v.is_view, v.orthogonalized = c0, n, True, 0
+        return v
 
     # --- shape -------------------------------------------------------------------------------
     def M(self):
@@ -289,6 +309,27 @@ class HipOperatorWrapper:
         check(ctx.lib.rails_csr_create(ctx.h, m, ncols_ext if ncols_ext is not None else m, rowptr.ctypes.data_as(C.POINTER(C.c_int64)),
                                        col.ctypes.data_as(C.POINTER(C.c_int32)), _p(val), C.byref(h)), "rails_csr_create")
         self.h = _Handle(ctx, h)
+
+    @classmethod
+    def from_callback(cls, ctx, m, pyfunc):
+        """An operator given by its action (include/rails_hip.h: rails_csr_create_callback): pyfunc(trans, X, Y) receives two
+        HipMultiVectorWrapper views (m x nc windows of the library's panels) and must set Y = op(A) X."""
+        def tramp(user, trans, xp, xc0, nc, yp, yc0):
+            try:
+                X = HipMultiVectorWrapper._borrow(ctx, xp, xc0, nc, m)
+                Y = HipMultiVectorWrapper._borrow(ctx, yp, yc0, nc, m)
+                return int(pyfunc(bool(trans), X, Y) or 0)
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = _lib.APPLY_FN(tramp)
+        h = C.c_void_p()
+        check(ctx.lib.rails_csr_create_callback(ctx.h, m, cb, None, C.byref(h)), "rails_csr_create_callback")
+        op = cls(ctx, None, None, None, _handle=_Handle(ctx, h))
+        op._apply_cb = cb  # keep the trampoline alive as long as the operator
+        op.h._keep = cb
+        return op
 
     def M(self):
         return self.ctx.lib.rails_csr_rows(self.h.h)

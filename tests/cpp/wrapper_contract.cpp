@@ -107,10 +107,11 @@ template <class MV>
 static bool orthonormal(MV const &a)
 {
     HostDenseMatrix G = a.dot(a);
+    double worst = 0.0;
     for (int i = 0; i < G.M(); ++i)
-        for (int j = 0; j < G.N(); ++j)
-            if (std::abs(G(i, j) - (i == j ? 1.0 : 0.0)) > 1e-14) return false;
-    return true;
+        for (int j = 0; j < G.N(); ++j) worst = std::max(worst, std::abs(G(i, j) - (i == j ? 1.0 : 0.0)));
+    if (!(worst <= 1e-14)) fprintf(stderr, "  orthonormal: %d columns, max |G - I| = %.3e\n", G.N(), worst);
+    return worst <= 1e-14;
 }
 
 template <class TR>
@@ -510,6 +511,44 @@ static void subspace_basis_cases(rails_ctx *ctx)
         SubspaceMultiVector c2 = SubspaceMultiVector::Absorb(basis, X);
         CHECK(basis->dim == 4);
         CHECK(same(c2.materialise(), X, 1e-13));
+    }
+    g_case = "Subspace.Basis full space and rounding-level directions";
+    {
+        // (a) the basis spans the whole space: whatever is absorbed next has only rounding error left after the projections, and
+        // none of it may enter the basis (a normalised rounding error is not orthogonal to P)
+        const int ms = 40;
+        auto basis = std::make_shared<SubspaceBasis>(ctx, ms, ms, 16);
+        SubspaceMultiVector a(basis, 20), b(basis, 20);
+        a.random();
+        b.random();
+        CHECK(basis->dim == ms);
+        CHECK(orthonormal(basis->P));
+        for (int rep = 0; rep < 3; ++rep) {
+            HipMultiVectorWrapper X(ms, 5, ctx);
+            X.random();
+            SubspaceMultiVector c = SubspaceMultiVector::Absorb(basis, X);
+            CHECK(basis->dim == ms);
+            CHECK(orthonormal(basis->P));
+            CHECK(same(c.materialise(), X, 1e-13));
+        }
+        // (b) a genuine direction 1e-11 below the part inside span(P) is kept, and kept orthogonal
+        auto basis2 = std::make_shared<SubspaceBasis>(ctx, m, m, 16);
+        SubspaceMultiVector p(basis2, 10);
+        p.random();
+        HipMultiVectorWrapper inside = p.materialise().copy(), D(m, 1, ctx);
+        D.random();
+        std::vector<double> hi = host_of(inside), hd = host_of(D), hx((size_t)m * 2);
+        for (int i = 0; i < m; ++i) {
+            hx[i] = hi[i + 2 * (size_t)m] - 0.5 * hi[i + 7 * (size_t)m] + 1e-11 * hd[i];
+            hx[i + (size_t)m] = hi[i + 4 * (size_t)m]; // and a column wholly inside
+        }
+        HipMultiVectorWrapper X2(m, 2, ctx);
+        X2.from_host(hx.data(), m);
+        const long delicate_before = basis2->n_delicate;
+        SubspaceMultiVector c = SubspaceMultiVector::Absorb(basis2, X2);
+        CHECK(basis2->dim == 11 && basis2->n_delicate == delicate_before + 1);
+        CHECK(orthonormal(basis2->P));
+        CHECK(same(c.materialise(), X2, 1e-13));
     }
     g_case = "Subspace.Basis growth and compress";
     {

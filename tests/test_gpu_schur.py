@@ -1,0 +1,120 @@
+"""Schur-complement operator for a singular diagonal mass matrix (rails_amd/schur.py; reference: src/SchurOperator.cpp:51-214) and
+the operator-callback handle of the C ABI it plugs in through (rails_csr_create_callback)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _descriptor_system(n1=40, n2=150, p=3, seed=0):
+    import scipy.sparse as sp
+
+    g = np.random.default_rng(seed)
+    n = n1 + n2
+    perm = g.permutation(n)
+    set1 = np.sort(perm[:n1])  # constraint unknowns scattered through the index range
+    mask1 = np.zeros(n, dtype=bool)
+    mask1[set1] = True
+    A = sp.random(n, n, density=0.04, random_state=np.random.RandomState(seed), format="lil")
+    A = (0.3 * A).tolil()
+    A.setdiag(np.where(mask1, 2.0 + g.uniform(0, 1, n), -4.0 - g.uniform(0, 1, n)))
+    A = A.tocsr()
+    A.sort_indices()
+    mass = np.where(mask1, 0.0, 1.0)
+    B = g.uniform(-1, 1, (n, p))
+    B[mask1] = 0.0
+    return (A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float64)), A.toarray(), mass, B, mask1
+
+
+def test_operator_callback_handle():
+    import rails_amd
+    from rails_amd.wrappers import HipMultiVectorWrapper as MV
+
+    ctx = rails_amd.Context(device=0, seed=2)
+    m = 500
+    g = np.random.default_rng(1)
+    D = g.uniform(1, 2, m)
+    calls = []
+
+    def apply(trans, X, Y):  # Y = diag(D) X through host memory: the callback sees windows of the caller's panels
+        calls.append((trans, X.n, X.c0, Y.c0))
+        Y.from_host(np.asfortranarray(D[:, None] * X.to_host()))
+        return 0
+
+    op = rails_amd.HipOperatorWrapper.from_callback(ctx, m, apply)
+    assert op.M() == m and op.nnz() == 0 and op.last_kernel() == "callback"
+    Xh = g.uniform(-1, 1, (m, 7))
+    big = MV(ctx, m=m, n=10, capacity=12)
+    X = big.view(2, 8)
+    X.from_host(Xh)
+    out = MV(ctx, m=m, n=9, capacity=9)
+    Y = out.view(1, 7)
+    op.apply(X, Y)
+    np.testing.assert_allclose(Y.to_host(), D[:, None] * Xh, rtol=0, atol=0)
+    assert calls[-1] == (False, 7, 2, 1)
+    op.transpose().apply(X, Y)
+    assert calls[-1][0] is True
+
+    def failing(trans, X, Y):
+        raise RuntimeError("boom")
+
+    bad = rails_amd.HipOperatorWrapper.from_callback(ctx, m, failing)
+    with pytest.raises(rails_amd.RailsError):
+        bad.apply(X, Y)
+    ctx.close()
+
+
+@pytest.mark.parametrize("subspace", [1, 0])
+def test_schur_operator_and_solve(subspace):
+    import scipy.linalg as sl
+
+    import rails_amd
+    from rails_amd.schur import SchurOperator
+    from rails_amd.wrappers import HipMultiVectorWrapper as MV
+
+    A, Ad, mass, B, mask1 = _descriptor_system()
+    ctx = rails_amd.Context(device=0, seed=4)
+    S = SchurOperator(ctx, A, mass)
+    i1, i2 = np.flatnonzero(mask1), np.flatnonzero(~mask1)
+    assert np.array_equal(S.idx1, i1) and np.array_equal(S.idx2, i2)
+    Sd = Ad[np.ix_(i2, i2)] - Ad[np.ix_(i2, i1)] @ np.linalg.solve(Ad[np.ix_(i1, i1)], Ad[np.ix_(i1, i2)])
+    np.testing.assert_allclose(S.dense(), Sd, atol=1e-12)
+    g = np.random.default_rng(2)
+    Xh = g.uniform(-1, 1, (S.m2, 5))
+    Y = S.op.apply(MV(ctx, data=Xh))
+    np.testing.assert_allclose(Y.to_host(), Sd @ Xh, atol=1e-12)
+    Yt = S.op.transpose().apply(MV(ctx, data=Xh))
+    np.testing.assert_allclose(Yt.to_host(), Sd.T @ Xh, atol=1e-12)
+    assert S.applies == 10  # matrix-vector products through the operator, as SchurOperator::GetMVPs counts them
+    # the Lyapunov equation on the Schur complement (what src/main.cpp:90-118 sets up): S X + X S' + B2 B2' = 0
+    B2 = S.restrict(B)
+    s = rails_amd.Solver(ctx, S.op, B2)
+    assert s.set_parameters({"Restart size": 60, "Reduced size": 30, "Expand size": 3, "Lanczos iterations": 5, "Tolerance": 1e-8}) == 0
+    s.set_option("verbose", 0)
+    s.set_option("subspace", subspace)
+    code, V, T = s.solve()
+    assert code == 0
+    X = V @ T @ V.T
+    Xref = sl.solve_continuous_lyapunov(Sd, -B2 @ B2.T)
+    assert np.linalg.norm(X - Xref) / np.linalg.norm(Xref) < 1e-6
+    assert s.relative_residual() < 1e-6
+    assert bool(s.backend_stats()) == bool(subspace)
+    # a general nonsingular part of the mass matrix: S X D + D X S' + B2 B2' = 0 with D = diag(M22)
+    mass2 = mass.copy()
+    mass2[~mask1] = g.uniform(0.5, 1.5, (~mask1).sum())
+    S2 = SchurOperator(ctx, A, mass2)
+    Dm = S2.mass22
+    Mop = rails_amd.HipOperatorWrapper(ctx, np.arange(S2.m2 + 1, dtype=np.int64), np.arange(S2.m2, dtype=np.int32), Dm)
+    s2 = rails_amd.Solver(ctx, S2.op, B2, M=Mop)
+    assert s2.set_parameters({"Restart size": 60, "Reduced size": 30, "Expand size": 3, "Lanczos iterations": 5, "Tolerance": 1e-8}) == 0
+    s2.set_option("verbose", 0)
+    s2.set_option("mass", 1)
+    s2.set_option("subspace", subspace)
+    code, V2, T2 = s2.solve()
+    assert code == 0
+    X2 = V2 @ T2 @ V2.T
+    R = Sd @ X2 * Dm[None, :] + (Dm[:, None] * X2) @ Sd.T + B2 @ B2.T
+    assert np.linalg.norm(R) / np.linalg.norm(B2 @ B2.T) < 1e-6
+    s.close()
+    s2.close()
+    ctx.close()
