@@ -4,9 +4,11 @@
     python -m torch.distributed.run --nproc-per-node N -m rails_amd.main ...      (one rank per GPU, rows partitioned)
 
 File names, formats and the parameter file follow the reference's driver (src/main.cpp:57-68,111,123-126): `A.mtx`, `B.mtx`
-and `M.mtx` in, `V.mtx` and `T.mtx` out, solver parameters from the "Lyapunov Solver" sublist of a Teuchos XML file.  What the
-reference's driver does around the solver with Trilinos -- the Schur complement for a singular mass matrix
-(src/SchurOperator.cpp) -- is outside this path: M must be absent (identity) or symmetric positive definite.
+and `M.mtx` in, `V.mtx` and `T.mtx` out, solver parameters from the "Lyapunov Solver" sublist of a Teuchos XML file.  A diagonal
+mass matrix with zeros on its diagonal (a descriptor system) is handled as the reference's driver does (src/main.cpp:77-99): the
+Lyapunov equation is solved on the Schur complement A22 - A21 A11^-1 A12 of the rows where M is nonzero (rails_amd/schur.py; one
+rank), B is restricted to those rows and V has that many rows.  Otherwise M must be absent (identity) or symmetric positive
+definite.
 """
 import argparse
 import os
@@ -101,8 +103,35 @@ def main(argv=None):
         op.set_halo(plan, partition.make_halo(plan, on_device=True))
         return op
 
+    schur = None
+    if Mcsr is not None:
+        mrp, mcol, mval = Mcsr
+        rows = np.repeat(np.arange(m), np.diff(mrp))
+        diagonal = bool(np.all(rows == mcol))
+        mdiag = np.zeros(m)
+        mdiag[rows[rows == mcol]] = mval[rows == mcol]
+        if diagonal and np.any(mdiag == 0.0):
+            if world > 1:
+                raise SystemExit("a singular mass matrix (Schur complement) runs on one rank, as in the reference (src/SchurOperator.cpp:226)")
+            from rails_amd.schur import SchurOperator
+
+            _log(rank, "Computing Schur complement")
+            t0 = time.time()
+            schur = SchurOperator(ctx, (rowptr, col, val), mdiag)
+            _log(rank, "  %d algebraic rows eliminated, %d remain; A11 factorised in %.2f s" % (schur.m1, schur.m2, time.time() - t0))
+            B = schur.restrict(B)
+            if V0 is not None and V0.shape[0] == m:
+                V0 = V0[schur.idx2]
+            d2 = schur.mass22
+            Mcsr = None if np.all(d2 == 1.0) else (np.arange(schur.m2 + 1, dtype=np.int64), np.arange(schur.m2, dtype=np.int64), d2)
+            m = schur.m2
+            r0, r1 = 0, m
+            ctx.set_partition(0, 1, 0, m)
+        elif not diagonal and np.any(mdiag == 0.0):
+            raise SystemExit("M has zero diagonal entries but is not diagonal: not supported")
+
     _log(rank, "Creating solver")
-    A = operator((rowptr, col, val))
+    A = schur.op if schur is not None else operator((rowptr, col, val))
     Mop = operator(Mcsr) if Mcsr else None
     if world > 1:
         ctx.set_allreduce(partition.make_allreduce(on_device=True))
@@ -125,6 +154,8 @@ def main(argv=None):
     ctx.sync()
     dt = time.perf_counter() - t0
     rel = solver.relative_residual()
+    if schur is not None:
+        _log(rank, "Amount of matrix-vector products after the solve: %d" % schur.applies)
     _log(rank, "solve returned %d after %d iterations in %.3f s: V is %d x %d, relative residual %.3e" % (code, solver.trips(), dt, m, solver.k, rel))
     if world > 1:
         parts = [None] * world

@@ -118,3 +118,35 @@ def test_schur_operator_and_solve(subspace):
     s.close()
     s2.close()
     ctx.close()
+
+
+def test_driver_with_singular_mass_matrix(tmp_path):
+    """python -m rails_amd.main with an M.mtx that has zero diagonal entries: the Schur-complement route of src/main.cpp:77-118"""
+    import os
+    import subprocess
+    import sys
+
+    import scipy.linalg as sl
+
+    from rails_amd import mmio
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    A, Ad, mass, B, mask1 = _descriptor_system(n1=30, n2=120, p=2, seed=3)
+    n = mass.size
+    mmio.write_csr(str(tmp_path / "A.mtx"), n, n, *A)
+    mmio.write_csr(str(tmp_path / "M.mtx"), n, n, np.arange(n + 1, dtype=np.int64), np.arange(n, dtype=np.int32), mass)  # explicit zeros
+    mmio.write_array(str(tmp_path / "B.mtx"), B)
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, "-m", "rails_amd.main", "--dir", str(tmp_path), "--set", "Tolerance=1e-8", "--set", "Restart size=60",
+                        "--set", "Reduced size=30", "--set", "Expand size=3", "--set", "Lanczos iterations=5"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert "Computing Schur complement" in p.stdout and "matrix-vector products" in p.stdout
+    V = mmio.read_dense(str(tmp_path / "V.mtx"))
+    T = mmio.read_dense(str(tmp_path / "T.mtx"))
+    i1, i2 = np.flatnonzero(mask1), np.flatnonzero(~mask1)
+    assert V.shape[0] == i2.size
+    Sd = Ad[np.ix_(i2, i2)] - Ad[np.ix_(i2, i1)] @ np.linalg.solve(Ad[np.ix_(i1, i1)], Ad[np.ix_(i1, i2)])
+    Xref = sl.solve_continuous_lyapunov(Sd, -B[i2] @ B[i2].T)
+    X = V @ T @ V.T
+    assert np.linalg.norm(X - Xref) / np.linalg.norm(Xref) < 1e-6
