@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <iostream>
 #include <memory>
 #include <vector>
@@ -52,10 +53,12 @@ inline bool hip_ok(int rc, const char *what)
 struct PanelHandle {
     rails_ctx *ctx;
     rails_panel *p;
-    PanelHandle(rails_ctx *c, int64_t m, int cap) : ctx(c), p(nullptr) { hip_ok(rails_panel_create(c, m, cap, &p), "rails_panel_create"); }
+    bool own;
+    PanelHandle(rails_ctx *c, int64_t m, int cap) : ctx(c), p(nullptr), own(true) { hip_ok(rails_panel_create(c, m, cap, &p), "rails_panel_create"); }
+    PanelHandle(rails_ctx *c, rails_panel *borrowed) : ctx(c), p(borrowed), own(false) {}
     ~PanelHandle()
     {
-        if (p) rails_panel_destroy(p);
+        if (p && own) rails_panel_destroy(p);
     }
     PanelHandle(PanelHandle const &) = delete;
     PanelHandle &operator=(PanelHandle const &) = delete;
@@ -107,6 +110,19 @@ public:
         out.replicated_ = true;
         out.hcap_ = std::max(n, 1);
         out.host_ = std::make_shared<std::vector<double>>((size_t)p * out.hcap_, 0.0);
+        return out;
+    }
+
+    // a view of columns [c0, c0 + n) of a panel somebody else owns (operator callbacks get their arguments this way)
+    static HipMultiVectorWrapper Window(rails_ctx *ctx, rails_panel *panel, int c0, int n)
+    {
+        HipMultiVectorWrapper out;
+        out.ctx_ = ctx;
+        out.panel_ = std::make_shared<PanelHandle>(ctx, panel);
+        out.m_ = rails_panel_rows(panel);
+        out.c0_ = c0;
+        out.n_ = n;
+        out.is_view_ = true;
         return out;
     }
 
@@ -433,6 +449,7 @@ struct CsrHandle {
     rails_ctx *ctx;
     rails_csr *A;
     bool own;
+    std::function<bool(bool, HipMultiVectorWrapper const &, HipMultiVectorWrapper &)> apply; // callback operators only
     CsrHandle(rails_ctx *c, rails_csr *a, bool o = true) : ctx(c), A(a), own(o) {}
     ~CsrHandle()
     {
@@ -469,6 +486,20 @@ public:
         if (A) h_ = std::make_shared<CsrHandle>(ctx_, A, false);
     }
 
+    // An operator given by its action: apply(transposed, X, Y) must write op(A) * X into Y (both are views of device panels, work
+    // on the context's stream) and return true.  The counterpart of wrapping any Epetra_Operator (src/Epetra_OperatorWrapper.cpp:75-91).
+    typedef std::function<bool(bool, HipMultiVectorWrapper const &, HipMultiVectorWrapper &)> ApplyFunction;
+    static HipOperatorWrapper FromCallback(rails_ctx *ctx, int64_t m_local, ApplyFunction apply, int64_t m_global = -1)
+    {
+        HipOperatorWrapper out;
+        out.ctx_ = ctx ? ctx : default_context();
+        out.m_global_ = m_global < 0 ? m_local : m_global;
+        auto h = std::make_shared<CsrHandle>(out.ctx_, nullptr);
+        h->apply = std::move(apply);
+        if (hip_ok(rails_csr_create_callback(out.ctx_, m_local, &HipOperatorWrapper::trampoline, h.get(), &h->A), "rails_csr_create_callback")) out.h_ = h;
+        return out;
+    }
+
     virtual ~HipOperatorWrapper() {}
 
     rails_csr *csr() const { return h_ ? h_->A : nullptr; }
@@ -485,6 +516,16 @@ public:
         return out;
     }
 
+private:
+    static int trampoline(void *user, int trans, const rails_panel *X, int xc0, int nc, rails_panel *Y, int yc0)
+    {
+        CsrHandle *h = static_cast<CsrHandle *>(user);
+        HipMultiVectorWrapper x = HipMultiVectorWrapper::Window(h->ctx, const_cast<rails_panel *>(X), xc0, nc);
+        HipMultiVectorWrapper y = HipMultiVectorWrapper::Window(h->ctx, Y, yc0, nc);
+        return h->apply(trans != 0, x, y) ? 0 : RAILS_EINVAL;
+    }
+
+public:
     // A * X (src/LyapunovSolver.hpp:146)
     HipMultiVectorWrapper operator*(HipMultiVectorWrapper const &X) const
     {

@@ -104,14 +104,14 @@ static bool same(MV const &a, MV const &b, double tol = 0.0)
     return true;
 }
 template <class MV>
-static bool orthonormal(MV const &a)
+static bool orthonormal(MV const &a, double tol = 1e-14)
 {
     HostDenseMatrix G = a.dot(a);
     double worst = 0.0;
     for (int i = 0; i < G.M(); ++i)
         for (int j = 0; j < G.N(); ++j) worst = std::max(worst, std::abs(G(i, j) - (i == j ? 1.0 : 0.0)));
-    if (!(worst <= 1e-14)) fprintf(stderr, "  orthonormal: %d columns, max |G - I| = %.3e\n", G.N(), worst);
-    return worst <= 1e-14;
+    if (!(worst <= tol)) fprintf(stderr, "  orthonormal: %d columns, max |G - I| = %.3e\n", G.N(), worst);
+    return worst <= tol;
 }
 
 template <class TR>
@@ -522,13 +522,13 @@ static void subspace_basis_cases(rails_ctx *ctx)
         a.random();
         b.random();
         CHECK(basis->dim == ms);
-        CHECK(orthonormal(basis->P));
+        CHECK(orthonormal(basis->P, 1e-12)); // 20 random vectors in the 20 dimensions left: an ill-conditioned block, rounding x 1 / min diag(R)
         for (int rep = 0; rep < 3; ++rep) {
             HipMultiVectorWrapper X(ms, 5, ctx);
             X.random();
             SubspaceMultiVector c = SubspaceMultiVector::Absorb(basis, X);
             CHECK(basis->dim == ms);
-            CHECK(orthonormal(basis->P));
+            CHECK(orthonormal(basis->P, 1e-12)); // 20 random vectors in the 20 dimensions left: an ill-conditioned block, rounding x 1 / min diag(R)
             CHECK(same(c.materialise(), X, 1e-13));
         }
         // (b) a genuine direction 1e-11 below the part inside span(P) is kept, and kept orthogonal
@@ -632,6 +632,37 @@ static void operator_cases(rails_ctx *ctx)
     for (int i = 0; i < n; ++i) mx = std::max(mx, std::sqrt(std::abs(D(i, 0))));
     CHECK(mx != 0.0);
     CHECK_NEAR(mx, E2.norm(), 1e-7 * mx); // power iteration on A'A: converged to the iteration's own stopping rule, not to the last bit
+    g_case = "Op.Callback";
+    {
+        // an operator given by its action (what wrapping any Epetra_Operator is in the reference, src/Epetra_OperatorWrapper.cpp:75-91):
+        // S = E2 - 0.5 I, computed from two library calls inside the callback
+        int calls = 0;
+        HipOperatorWrapper S = HipOperatorWrapper::FromCallback(ctx, n, [&](bool trans, HipMultiVectorWrapper const &X, HipMultiVectorWrapper &Y) {
+            ++calls;
+            Y = (trans ? E2.transpose() : E2) * X; // assignment to a view copies in
+            Y -= 0.5 * X;
+            return true;
+        });
+        CHECK(S.M() == n && S.csr() != nullptr);
+        HipMultiVectorWrapper x(n, 3, ctx);
+        x.random();
+        HipMultiVectorWrapper y = S * x, ref = E2 * x;
+        ref -= 0.5 * x;
+        CHECK(calls == 1 && same(y, ref, 1e-14));
+        HipMultiVectorWrapper yt = S.transpose() * x, reft = E2.transpose() * x;
+        reft -= 0.5 * x;
+        CHECK(calls == 2 && same(yt, reft, 1e-14));
+        // the same handle under the coordinate-space operator
+        auto basis = std::make_shared<SubspaceBasis>(ctx, n, n, 16);
+        SubspaceOperator Ss(S, basis);
+        SubspaceMultiVector xs = SubspaceMultiVector::Absorb(basis, x);
+        SubspaceMultiVector ys = Ss * xs;
+        CHECK(calls == 3 && same(ys.materialise(), ref, 1e-13));
+        // a failing callback is an error of the product, not a crash
+        HipOperatorWrapper bad = HipOperatorWrapper::FromCallback(ctx, n, [](bool, HipMultiVectorWrapper const &, HipMultiVectorWrapper &) { return false; });
+        HipMultiVectorWrapper out(n, 3, ctx);
+        CHECK(!bad.apply_into(x, out, 0));
+    }
 }
 
 static void dense_cases()
