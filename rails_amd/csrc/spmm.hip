@@ -445,6 +445,7 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
             rails_set_error("rails_spmm: the operator callback failed with code %d", rc);
             return RAILS_ECOMM;
         }
+        c->n_spmm_callback++;
         return RAILS_OK;
     }
     if (trans) {

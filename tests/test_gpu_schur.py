@@ -54,6 +54,7 @@ def test_operator_callback_handle():
     assert calls[-1] == (False, 7, 2, 1)
     op.transpose().apply(X, Y)
     assert calls[-1][0] is True
+    assert ctx.stats()["spmm_callback"] == 2
 
     def failing(trans, X, Y):
         raise RuntimeError("boom")
