@@ -149,7 +149,7 @@ template <int LPR, int RPG>
 __global__ __launch_bounds__(256) void k_spmm_rowgather_cc(int64_t m, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                            const double *__restrict__ val, const double *__restrict__ X, int ldx,
                                                            const double *__restrict__ Xg, int ldg, double *__restrict__ Y, int ldy, int nc,
-                                                           int64_t blocks_per_xcd, int lds_cap)
+                                                           int64_t blocks_per_xcd, int lds_cap, int y_vec)
 {
     constexpr int GROUPS = 256 / LPR;
     constexpr int ROWS = GROUPS * RPG;
@@ -216,15 +216,18 @@ __global__ __launch_bounds__(256) void k_spmm_rowgather_cc(int64_t m, const int6
             }
         }
         double *dst = Y + row * ldy + cb;
-        if (full)
+        if (full && y_vec)
             *reinterpret_cast<double2_t *>(dst) = acc;
-        else
+        else if (full) { // Y window starts on an odd column: two 8-byte stores
+            dst[0] = acc.x;
+            dst[1] = acc.y;
+        } else
             *dst = acc.x;
     }
 }
 
 template <int LPR>
-int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc)
+int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool y_vec = true)
 {
     constexpr int GROUPS = 256 / LPR;
     constexpr int RPG = (LPR >= 32) ? 8 : (LPR >= 16 ? 4 : 2);
@@ -237,7 +240,7 @@ int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, con
     RAILS_REQUIRE(grid <= 0x7fffffffLL, "rails_spmm: grid too large");
     const int lds_cap = 2048; // nonzeros of one block staged in LDS (24 KiB); longer runs read (col, val) from global memory
     hipLaunchKernelGGL((k_spmm_rowgather_cc<LPR, RPG>), dim3((unsigned)grid), dim3(256), (size_t)lds_cap * 12, c->stream, A->m, A->rowptr,
-                       A->col, A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx, lds_cap);
+                       A->col, A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx, lds_cap, y_vec ? 1 : 0);
     return RAILS_OK;
 }
 
@@ -501,11 +504,15 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         // in LDS instead of per-lane vector-memory loads: 0.38 vs 0.45 ms at 16 columns (banded), 0.37 vs 0.42 (stencil); at 32
         // columns the two forms tie, so that stays with the plain kernel (RAILS_SPMM_NARROW_CC=0 disables, =2 also takes 32)
         static const int narrow_env = spmm_env("RAILS_SPMM_NARROW_CC", 1);
-        if (cc == 0 && vec2 && narrow_env && A->variant != 3 && nc > 8 && nc <= (narrow_env == 2 ? 32 : 16) && A->max_row_nnz <= 64) cc = nc <= 16 ? 16 : -32;
+        // (the gathers need 16-byte aligned X rows; a Y window on an odd column -- A*W written behind an odd number of basis columns --
+        // only changes the form of the stores)
+        const bool x_vec2 = (xc0 & 1) == 0 && (X->ld % 2 == 0) && (ldg % 2 == 0);
+        const bool y_vec2 = (yc0 & 1) == 0 && (Y->ld % 2 == 0);
+        if (cc == 0 && x_vec2 && narrow_env && A->variant != 3 && nc > 8 && nc <= (narrow_env == 2 ? 32 : 16) && A->max_row_nnz <= 64) cc = nc <= 16 ? 16 : -32;
         if (cc == 16)
-            RAILS_TRY((launch_rg_cc<8>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
+            RAILS_TRY((launch_rg_cc<8>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, y_vec2)));
         else if (cc == -32)
-            RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
+            RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, y_vec2)));
         else if (cc == 32)
             RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
         else if (cc == 64)

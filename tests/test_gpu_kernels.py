@@ -84,7 +84,7 @@ def test_spmm_matches_oracle(ctx, oracle, name):
     op = rails_amd.HipOperatorWrapper(ctx, *A)
     g = np.random.default_rng(11)
     nnz_row = max(1, A[1].size // m)
-    for nc, xoff, yoff in ((1, 0, 0), (3, 0, 0), (8, 0, 2), (16, 16, 0), (17, 1, 0), (64, 0, 1), (128, 0, 0), (130, 2, 4)):
+    for nc, xoff, yoff in ((1, 0, 0), (3, 0, 0), (8, 0, 2), (16, 16, 0), (16, 0, 3), (11, 2, 5), (17, 1, 0), (64, 0, 1), (128, 0, 0), (130, 2, 4)):
         Xh = g.uniform(-1, 1, (m, nc))
         big = MV(ctx, m=m, n=nc + xoff, capacity=nc + xoff)
         X = big.view(xoff, xoff + nc - 1) if nc > 1 else big.view(xoff)
