@@ -305,7 +305,10 @@ def main():
                        "parallelism": "row-partition x%d, RCCL all-reduce of projected blocks" % nranks if nranks > 1 else "single GPU",
                        "spmm_columns": kk, "residual_lanczos": ("the reference's recurrence on coordinate vectors (host)" if args.subspace else
                                             ("coefficient-space, Gram differences" if args.projected_lanczos else "fused one-pass-per-step kernel")),
-                       "backend": "coordinates in a device-resident orthonormal basis" if args.subspace else "direct panels"},
+                       "backend": "coordinates in a device-resident orthonormal basis" if args.subspace else "direct panels",
+                       # one JOINT solve over n_gpus x m rows: under weak scaling the ideal is a constant iteration rate; the rate at which
+                       # matrix rows are processed (rows x iterations / s) is the quantity that grows with the GPU count
+                       "global_rows": int(mg), "row_iterations_per_s": its * mg},
             "roofline": {"bound": "hbm", "kernel": spmm_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms},
             "cpu_baseline": cpu,
