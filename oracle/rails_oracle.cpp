@@ -810,7 +810,15 @@ int orc_solve(int m, const double *Adense, int lda, const int64_t *rp, const int
                     L[i + (size_t)j * k] = 0.5 * (VMV[i + (size_t)j * ldS] + VMV[j + (size_t)i * ldS]);
             int info = 0;
             g_lapack.dpotrf("L", &k, L.data(), &k, &info);
-            if (info) fprintf(stderr, "rails_oracle: VMV not SPD (dpotrf info %d)\n", info);
+            double sgn = 1.0;
+            if (info) { // negative definite M: the equation is invariant under (A, M) -> (-A, -M)
+                sgn = -1.0;
+                for (int j = 0; j < k; ++j)
+                    for (int i = 0; i < k; ++i)
+                        L[i + (size_t)j * k] = -0.5 * (VMV[i + (size_t)j * ldS] + VMV[j + (size_t)i * ldS]);
+                g_lapack.dpotrf("L", &k, L.data(), &k, &info);
+            }
+            if (info) fprintf(stderr, "rails_oracle: VMV neither positive nor negative definite (dpotrf info %d)\n", info);
             auto lsolve_left = [&](std::vector<double> &X) { // X <- L^-1 X
                 for (int j = 0; j < k; ++j)
                     for (int i = 0; i < k; ++i) {
@@ -829,7 +837,7 @@ int orc_solve(int m, const double *Adense, int lda, const int64_t *rp, const int
             };
             for (int j = 0; j < k; ++j)
                 for (int i = 0; i < k; ++i) {
-                    Ai[i + (size_t)j * k] = VAV[i + (size_t)j * ldS];
+                    Ai[i + (size_t)j * k] = sgn * VAV[i + (size_t)j * ldS];
                     Bi[i + (size_t)j * k] = VBV[i + (size_t)j * ldS];
                 }
             lsolve_left(Ai);

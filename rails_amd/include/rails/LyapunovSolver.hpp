@@ -489,7 +489,7 @@ public:
 
     // T = lyap(VAV, VBV, [], VMV):  VAV T VMV' + VMV T VAV' + VBV = 0      (matlab/RAILSsolver.m:382,
     // matlab/mex/lyap.c:125-133 call SLICOT sg03ad).  Reduced to the standard equation with the Cholesky
-    // factor VMV = L L':  (L^-1 VAV L^-T) Tt + Tt (..)' + L^-1 VBV L^-T = 0,  T = L^-T Tt L^-1.
+    // factor VMV = L L':  (L^-1 VAV L^-T) Tt + Tt (..)' + L^-1 VBV L^-T = 0,  T = L^-T Tt L^-1.  M symmetric definite (either sign).
     int generalized_dense_solve(DenseMatrix const &A, DenseMatrix const &B, DenseMatrix const &Mm, DenseMatrix &X)
     {
         int k = A.M();
@@ -503,7 +503,18 @@ public:
         int info = 0;
         rails_dpotrf('L', k, L, L.LDA(), &info);
         if (info) {
-            std::cerr << "Error: projected mass matrix is not positive definite (dpotrf info = " << info << ")" << std::endl;
+            // The equation does not change under (A, M) -> (-A, -M): a negative definite mass matrix (the reference's MOC data set,
+            // matlab/DataErik/Bp1.co, is one) is the definite case with both signs flipped.  SLICOT's sg03ad takes any nonsingular
+            // M; an indefinite one is not supported here.
+            for (int j = 0; j < k; ++j)
+                for (int i = 0; i < k; ++i) {
+                    L(i, j) = -0.5 * (Mm(i, j) + Mm(j, i));
+                    Ai(i, j) = -A(i, j);
+                }
+            rails_dpotrf('L', k, L, L.LDA(), &info);
+        }
+        if (info) {
+            std::cerr << "Error: projected mass matrix is neither positive nor negative definite (dpotrf info = " << info << ")" << std::endl;
             return info;
         }
         auto left = [&](DenseMatrix &Y) { // Y <- L^-1 Y

@@ -7,6 +7,11 @@ file formats: `%%MatrixMarket matrix coordinate real|integer|pattern general|sym
 are summed, as Epetra's insertion does), `%%MatrixMarket matrix array real general` <-> dense column-major arrays, and the
 Teuchos `<ParameterList>` XML (or a JSON object with the same names).
 
+The data set of the reference's application test (matlab/DataErik/, read by matlab/test/test_MOC.m:94-121) uses a second, plain
+text format: `<name>.info` (n nnz), `<name>.beg` (n + 1 row starts, 1-based), `<name>.jco` (column indices, 1-based), `<name>.co`
+(values), and single-column `.co` files for diagonals and vectors; `read_csr` / `read_dense` take those too (a path without
+`.mtx` whose `.beg` file exists; a `.co` file).
+
 Host-side only; nothing here touches the GPU.
 """
 import io
@@ -114,7 +119,45 @@ def read(path):
         return "csr", (m, n) + coo_to_csr(m, n, rows, cols, vals)
 
 
+def _column(path):
+    with open(path, "r") as f:
+        return _numbers(f, 1).ravel()
+
+
+def read_begjco(stem):
+    """CSR matrix from <stem>.info / .beg / .jco / .co (matlab/test/test_MOC.m:94-121) -> (m, n, rowptr, col, val)"""
+    n, nnz = (int(x) for x in _column(stem + ".info")[:2])
+    beg = _column(stem + ".beg").astype(np.int64)
+    jco = _column(stem + ".jco").astype(np.int64)
+    co = _column(stem + ".co")
+    if beg.size != n + 1 or beg[0] != 1 or beg[-1] != nnz + 1 or np.any(np.diff(beg) < 0):
+        raise MatrixMarketError("%s.beg does not hold %d + 1 ascending row starts ending at nnz + 1" % (stem, n))
+    if jco.size != nnz or co.size != nnz or (nnz and (jco.min() < 1 or jco.max() > n)):
+        raise MatrixMarketError("%s.jco / .co do not hold %d entries with column indices in 1..%d" % (stem, nnz, n))
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(beg))
+    return (n, n) + coo_to_csr(n, n, rows, jco - 1, co)
+
+
+def write_begjco(stem, rowptr, col, val):
+    n = len(rowptr) - 1
+    with open(stem + ".info", "w") as f:
+        f.write("%12d%12d\n" % (n, len(val)))
+    np.savetxt(stem + ".beg", np.asarray(rowptr, dtype=np.int64) + 1, fmt="%12d")
+    np.savetxt(stem + ".jco", np.asarray(col, dtype=np.int64) + 1, fmt="%12d")
+    np.savetxt(stem + ".co", np.asarray(val, dtype=np.float64), fmt="%26.16E")
+
+
+def _is_begjco(path):
+    return not path.endswith(".mtx") and os.path.exists(path + ".beg")
+
+
 def read_csr(path):
+    if _is_begjco(path):
+        return read_begjco(path)
+    if path.endswith(".co"):  # a diagonal (matlab/test/test_MOC.m:122: M = sparse(1:n, 1:n, Mco))
+        d = _column(path)
+        n = d.size
+        return n, n, np.arange(n + 1, dtype=np.int64), np.arange(n, dtype=np.int32), d
     kind, data = read(path)
     if kind == "dense":
         m, n = data.shape
@@ -125,6 +168,8 @@ def read_csr(path):
 
 def read_dense(path):
     """Dense m x n array from either an array file or a (sparse) coordinate file, e.g. the reference's B.mtx."""
+    if path.endswith(".co"):  # one column of numbers
+        return np.asfortranarray(_column(path)[:, None])
     kind, data = read(path)
     if kind == "dense":
         return data

@@ -61,8 +61,21 @@ class SchurOperator:
         return 0
 
     def restrict(self, B):
-        """rows of B on the set-2 unknowns (the reference imports B into the Schur operator's range map, src/main.cpp:83-88)"""
-        return np.asfortranarray(np.asarray(B)[self.idx2])
+        """B on the set-2 unknowns: B2 - A21 A11^-1 B1 (matlab/RAILSschur.m:47-53,71-73; the reference's C++ driver imports the rows of
+        B into the Schur operator's range map, src/main.cpp:83-88, which is the same thing when B vanishes on set 1)"""
+        B = np.asarray(B, dtype=np.float64)
+        B2 = B[self.idx2]
+        if self.m1 and np.abs(B[self.idx1]).max() > np.sqrt(np.finfo(float).eps):
+            B2 = B2 - self.A21 @ self.lu.solve(np.ascontiguousarray(B[self.idx1]))
+        return np.asfortranarray(B2)
+
+    def prolongate(self, V):
+        """the solution on all unknowns from the solution on set 2: x1 = -A11^-1 A12 x2 (matlab/RAILSschur.m:75-77); X = Vf T Vf'"""
+        V = np.asarray(V, dtype=np.float64)
+        out = np.zeros((self.m1 + self.m2, V.shape[1]), order="F")
+        out[self.idx2] = V
+        out[self.idx1] = -self.lu.solve(np.ascontiguousarray(self.A12 @ V))
+        return out
 
     def dense(self):
         """the Schur complement as a dense matrix (tests, small problems)"""

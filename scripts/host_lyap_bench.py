@@ -51,3 +51,26 @@ for n in (128, 144, 160, 176, 192, 200, 256):
     t_syl = best(lambda: lapack.dtrsyl(S, S, F, trana="N", tranb="T"))
     t_gemm = best(lambda: U.T @ Cm @ U)
     print("n=%3d  rails_sb03md %6.2f ms (symmetric A: %5.2f) | dgees %6.2f (dgehrd %5.2f) | dtrsyl %5.2f | 2 dgemm %5.2f" % (n, t_sb, t_sym, t_gees, t_hrd, t_syl, t_gemm), flush=True)
+
+# restart-side host numerics: eig(T) of the k x k solution and the pivoted QR of compress()
+for n in (128, 200, 256):
+    Sm = rng.standard_normal((n, n))
+    T = np.asfortranarray(Sm + Sm.T)
+    w = np.zeros(n)
+
+    def ev():
+        Tp, info = T.copy(order="F"), C.c_int(0)
+        lib.rails_dsyev(b"V", b"U", n, Tp.ctypes.data_as(dp), n, w.ctypes.data_as(dp), C.byref(info))
+    t_ev = best(ev)
+    t_evr = best(lambda: lapack.dsyevr(T))
+    t_evd = best(lambda: lapack.dsyevd(T))
+    print("n=%3d  rails_dsyev %5.2f ms | scipy dsyevd %5.2f | dsyevr %5.2f" % (n, t_ev, t_evd, t_evr), flush=True)
+for dim, ncols in ((354, 300), (450, 330)):
+    Cc = np.asfortranarray(rng.standard_normal((dim, 160)) @ rng.standard_normal((160, ncols)))  # rank 160 of ncols columns
+    Q = np.zeros((dim, min(dim, ncols)), order="F")
+
+    def rb():
+        Cp, rank, info = Cc.copy(order="F"), C.c_int(0), C.c_int(0)
+        lib.rails_range_basis(dim, ncols, Cp.ctypes.data_as(dp), dim, C.c_double(1e-14), Q.ctypes.data_as(dp), dim, C.byref(rank), C.byref(info))
+        return rank.value
+    print("range_basis %d x %d (rank %d): %5.2f ms" % (dim, ncols, rb(), best(rb)), flush=True)
