@@ -2,7 +2,7 @@
 """Run the BASELINE.json configurations that fit one GPU to convergence (SURVEY.md section 8(d) definitions) and
 print one JSON line per configuration: trips, wall time, iterations/s, V.N(), relative residual, kernel counters.
 
-    python scripts/run_configs.py [c1 c2 c3 c3s c4slab c5]
+    [RAILS_RUN_SUBSPACE=1] [RAILS_RUN_TOL=1e-8] python scripts/run_configs.py [c1 c2 c3 c3s c3u c4slab c5]
 
 c3  = banded-random (SURVEY primary), c3s = the same size with the 27-point stencil pattern, c4slab = ONE rank's share of
 config 4 (27-point stencil, 1M rows, B m x 32, Restart 256 / Reduced 128 / Expand 32 / Lanczos 40) on one GPU,
@@ -22,6 +22,8 @@ def run(ctx, name, A, B, params, M=None, V0=None, max_trips=400, seed=1):
     import rails_amd
 
     ctx.set_seed(seed, 0)
+    if os.environ.get("RAILS_RUN_TOL"):  # the same configurations at another tolerance (robustness sweeps)
+        params = dict(params, Tolerance=float(os.environ["RAILS_RUN_TOL"]))
     op = rails_amd.HipOperatorWrapper(ctx, *A)
     mop = rails_amd.HipOperatorWrapper(ctx, *M) if M is not None else None
     s = rails_amd.Solver(ctx, op, B, M=mop)
@@ -66,6 +68,9 @@ def main():
     if "c3s" in which:
         A = P.stencil27(100, 100, 100, random_values=True, seed=1)
         run(ctx, "C3 stencil-27 pattern m=1M", A, P.rhs(1000000, 16, seed=8), prm3)
+    if "c3u" in which:  # SURVEY 8(d)'s secondary pattern: uniformly random columns (report-only)
+        A = P.uniform_random(1000000, 27, seed=1)
+        run(ctx, "C3 uniform-random m=1M", A, P.rhs(1000000, 16, seed=8), prm3)
     if "c4slab" in which:
         A = P.stencil27(200, 200, 25)
         run(ctx, "C4 one rank's slab 200x200x25 on one GPU", A, P.rhs(1000000, 32, seed=9),

@@ -369,3 +369,26 @@ def test_subspace_backend_mass_matrix_and_warm_start(ctx, oracle):
     Xb, Xc = Vb @ Tb @ Vb.T, Vc @ Tc @ Vc.T
     assert np.linalg.norm(Xb - Xc) / np.linalg.norm(Xc) < 1e-2
     assert sb.relative_residual() < 1e-3
+
+
+def test_subspace_backend_long_stagnating_run_stays_orthonormal(ctx):
+    """A tolerance the restart size cannot reach: hundreds of trips of restarts and small-survival A*W blocks.  The basis must stay
+    orthonormal (a looser re-orthogonalisation rule than DGKS let V'V - I grow to 6e-7 after 200 trips and 0.9 after 400 here) and the
+    stagnation level must be the direct back end's."""
+    from rails_amd import problems as P
+
+    Ad = P.dense_stable(256, seed=1)
+    A = P.dense_to_csr(Ad)
+    B = P.rhs(256, 4, seed=2)
+    params = {"Restart size": 32, "Reduced size": 16, "Expand size": 3, "Lanczos iterations": 10, "Tolerance": 1e-8}
+    res = {}
+    for name, opts in (("subspace", SUB), ("direct", None)):
+        code, V, T, s = _solve(ctx, A, B, params, seed=1, options={**(opts or {}), "max_trips": 300})
+        assert code == 2 and s.trips() == 300  # bounded run, not converged
+        assert np.abs(V.T @ V - np.eye(V.shape[1])).max() < 1e-12
+        res[name] = np.linalg.norm(_residual(Ad, B, V, T), 2) / np.linalg.norm(B.T @ B, 2)
+        if opts:
+            st = s.backend_stats()
+            assert st["second_rounds"] > 100 and st["compress"] > 20
+    # the level moves with the position in the restart cycle; the two back ends sit at the same place of the same cycle
+    assert res["subspace"] < 5e-3 and 0.5 < res["subspace"] / res["direct"] < 2.0
