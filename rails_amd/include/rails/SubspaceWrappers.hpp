@@ -11,9 +11,9 @@
 //     orthonormalise the tail against P: block CGS2 + CholQR2, coefficients by bookkeeping) and `random()` (fill, project);
 //   * after a restart the live coefficient matrices span fewer directions than P holds: compress() re-bases P on an
 //     orthonormal basis of their column space (pivoted Householder QR on the host, one panel GEMM on the device).
-// Per RAILS trip that is ~3 passes over the m x dim basis (materialise W, one Gram, one update; the Lanczos start vector of the
-// next trip rides in the A*W block) instead of the 21 passes over [AV V B] of the fused Lanczos kernel plus the projection /
-// orthogonalisation passes of the direct back end (HipWrappers.hpp), and 3-5 all-reduces instead of ~31.
+// Per RAILS trip that is ~5 passes over the m x dim basis (materialise W, two rounds of Gram + update; the Lanczos start vector of
+// the next trip rides in the A*W block) instead of the 21 passes over [AV V B] of the fused Lanczos kernel plus the projection /
+// orthogonalisation passes of the direct back end (HipWrappers.hpp), and 5 all-reduces instead of ~31.
 //
 // The classes satisfy the same duck-typed contract as HipMultiVectorWrapper / HipOperatorWrapper, so the
 // unmodified solver template -- the reference's member-by-member sequence, src/LyapunovSolver.hpp:100-482 -- runs on them.
