@@ -221,6 +221,9 @@ void rails_dsteqr(char compz, int n, double *d, double *e, double *z, int ldz, d
 /* src/BlasWrapper.hpp:34-42 (DGEMM), for the small host products of the restart (X' (VAV X), src/LyapunovSolver.hpp:286) */
 void rails_dgemm(char transa, char transb, int m, int n, int k, double alpha, const double *A, int lda, const double *B,
                  int ldb, double beta, double *C, int ldc);
+/* Triangular solve with many right-hand sides (BLAS DTRSM; src/BlasWrapper.hpp has no counterpart -- the generalized projected
+ * solve, matlab/mex/lyap.c:125-133, reduces with the Cholesky factor of V'MV through it) */
+void rails_dtrsm(char side, char uplo, char transa, char diag, int m, int n, double alpha, const double *A, int lda, double *B, int ldb);
 /* Cholesky (generalized projected solve, block orthogonalisation) */
 void rails_dpotrf(char uplo, int n, double *a, int lda, int *info);
 /* Cholesky with complete pivoting of a positive semi-definite matrix (LAPACK dpstrf): P'AP = R'R, stops at the first pivot

@@ -39,6 +39,8 @@ typedef void (*lp_dorgqr)(const int *, const int *, const int *, double *, const
 typedef void (*lp_dpstrf)(const char *, const int *, double *, const int *, int *, int *, const double *, double *, int *);
 typedef void (*lp_dgemm)(const char *, const char *, const int *, const int *, const int *, const double *, const double *,
                          const int *, const double *, const int *, const double *, double *, const int *);
+typedef void (*lp_dtrsm)(const char *, const char *, const char *, const char *, const int *, const int *, const double *, const double *,
+                         const int *, double *, const int *);
 }
 
 struct HostLapack {
@@ -55,6 +57,7 @@ struct HostLapack {
     lp_dgeqp3 dgeqp3 = nullptr; // optional (rails_range_basis)
     lp_dorgqr dorgqr = nullptr;
     lp_dgemm dgemm = nullptr;
+    lp_dtrsm dtrsm = nullptr; // optional: the generalized projected solve falls back to loops
 } g_lp;
 std::mutex g_lp_mutex;
 
@@ -84,6 +87,7 @@ bool try_open(const std::string &path)
     L.dtrsyl3 = (lp_dtrsyl3)lookup(h, "dtrsyl3_");
     L.dpotrf = (lp_dpotrf)lookup(h, "dpotrf_");
     L.dgemm = (lp_dgemm)lookup(h, "dgemm_");
+    L.dtrsm = (lp_dtrsm)lookup(h, "dtrsm_");
     L.dpstrf = (lp_dpstrf)lookup(h, "dpstrf_");
     L.dgeqp3 = (lp_dgeqp3)lookup(h, "dgeqp3_");
     L.dorgqr = (lp_dorgqr)lookup(h, "dorgqr_");
@@ -200,6 +204,56 @@ extern "C" void rails_dsteqr(char compz, int n, double *d, double *e, double *z,
         return;
     }
     g_lp.dsteqr(&compz, &n, d, e, z, &ldz, work, info);
+}
+
+// B <- alpha * op(A)^-1 B (side 'L') or alpha * B op(A)^-1 (side 'R'), A triangular: BLAS DTRSM, or plain loops when the library has none
+extern "C" void rails_dtrsm(char side, char uplo, char transa, char diag, int m, int n, double alpha, const double *A, int lda, double *B, int ldb)
+{
+    if (m <= 0 || n <= 0) return;
+    const char *force_loops = getenv("RAILS_DTRSM_LOOPS"); // tests: exercise the fallback
+    if (!(force_loops && atoi(force_loops) != 0) && rails_host_lapack_init(nullptr) == RAILS_OK && g_lp.dtrsm) {
+        g_lp.dtrsm(&side, &uplo, &transa, &diag, &m, &n, &alpha, A, &lda, B, &ldb);
+        return;
+    }
+    const bool left = side == 'L' || side == 'l', upper = uplo == 'U' || uplo == 'u', trans = !(transa == 'N' || transa == 'n'),
+               unit = diag == 'U' || diag == 'u';
+    const int na = left ? m : n;
+    auto a = [&](int i, int j) { return trans ? A[j + (size_t)i * lda] : A[i + (size_t)j * lda]; }; // op(A)(i, j)
+    const bool op_upper = upper != trans;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < m; ++i) B[i + (size_t)j * ldb] *= alpha;
+    if (left) { // solve op(A) X = B column by column
+        for (int j = 0; j < n; ++j) {
+            double *b = B + (size_t)j * ldb;
+            if (op_upper)
+                for (int i = na - 1; i >= 0; --i) {
+                    double s = b[i];
+                    for (int l = i + 1; l < na; ++l) s -= a(i, l) * b[l];
+                    b[i] = unit ? s : s / a(i, i);
+                }
+            else
+                for (int i = 0; i < na; ++i) {
+                    double s = b[i];
+                    for (int l = 0; l < i; ++l) s -= a(i, l) * b[l];
+                    b[i] = unit ? s : s / a(i, i);
+                }
+        }
+    } else { // solve X op(A) = B row by row
+        for (int i = 0; i < m; ++i) {
+            if (op_upper)
+                for (int j = 0; j < na; ++j) {
+                    double s = B[i + (size_t)j * ldb];
+                    for (int l = 0; l < j; ++l) s -= B[i + (size_t)l * ldb] * a(l, j);
+                    B[i + (size_t)j * ldb] = unit ? s : s / a(j, j);
+                }
+            else
+                for (int j = na - 1; j >= 0; --j) {
+                    double s = B[i + (size_t)j * ldb];
+                    for (int l = j + 1; l < na; ++l) s -= B[i + (size_t)l * ldb] * a(l, j);
+                    B[i + (size_t)j * ldb] = unit ? s : s / a(j, j);
+                }
+        }
+    }
 }
 
 extern "C" void rails_dgemm(char ta, char tb, int m, int n, int k, double alpha, const double *A, int lda, const double *B, int ldb,

@@ -517,40 +517,15 @@ public:
             std::cerr << "Error: projected mass matrix is neither positive nor negative definite (dpotrf info = " << info << ")" << std::endl;
             return info;
         }
-        auto left = [&](DenseMatrix &Y) { // Y <- L^-1 Y
-            for (int j = 0; j < k; ++j)
-                for (int i = 0; i < k; ++i) {
-                    double s = Y(i, j);
-                    for (int l = 0; l < i; ++l) s -= L(i, l) * Y(l, j);
-                    Y(i, j) = s / L(i, i);
-                }
-        };
-        auto right = [&](DenseMatrix &Y) { // Y <- Y L^-T
-            for (int i = 0; i < k; ++i)
-                for (int j = 0; j < k; ++j) {
-                    double s = Y(i, j);
-                    for (int l = 0; l < j; ++l) s -= Y(i, l) * L(j, l);
-                    Y(i, j) = s / L(j, j);
-                }
-        };
-        left(Ai);
-        right(Ai);
-        left(Bi);
-        right(Bi);
+        // (L^-1 A L^-T, L^-1 B L^-T), solve, T = L^-T Tt L^-1: six triangular solves with k right-hand sides each
+        rails_dtrsm('L', 'L', 'N', 'N', k, k, 1.0, L, L.LDA(), Ai, Ai.LDA());
+        rails_dtrsm('R', 'L', 'T', 'N', k, k, 1.0, L, L.LDA(), Ai, Ai.LDA());
+        rails_dtrsm('L', 'L', 'N', 'N', k, k, 1.0, L, L.LDA(), Bi, Bi.LDA());
+        rails_dtrsm('R', 'L', 'T', 'N', k, k, 1.0, L, L.LDA(), Bi, Bi.LDA());
         DenseMatrix Tt;
         int ret = dense_solve(Ai, Bi, Tt);
-        for (int j = 0; j < k; ++j) // Tt <- L^-T Tt
-            for (int i = k - 1; i >= 0; --i) {
-                double s = Tt(i, j);
-                for (int l = i + 1; l < k; ++l) s -= L(l, i) * Tt(l, j);
-                Tt(i, j) = s / L(i, i);
-            }
-        for (int i = 0; i < k; ++i) // Tt <- Tt L^-1
-            for (int j = k - 1; j >= 0; --j) {
-                double s = Tt(i, j);
-                for (int l = j + 1; l < k; ++l) s -= Tt(i, l) * L(l, j);
-                Tt(i, j) = s / L(j, j);
-            }
+        rails_dtrsm('L', 'L', 'T', 'N', k, k, 1.0, L, L.LDA(), Tt, Tt.LDA());
+        rails_dtrsm('R', 'L', 'N', 'N', k, k, 1.0, L, L.LDA(), Tt, Tt.LDA());
         X = Tt;
         return ret;
     }

@@ -132,6 +132,38 @@ def test_host_dsyev_and_dsteqr():
     np.testing.assert_allclose(dd, w, atol=1e-13)
 
 
+@pytest.mark.parametrize("loops", [0, 1])
+def test_host_dtrsm_all_forms(loops, monkeypatch):
+    """rails_dtrsm (the six triangular solves of the generalized projected solve): BLAS path and the loop fallback, every
+    side / uplo / trans / diag combination, leading dimensions larger than the sizes"""
+    import scipy.linalg as sl
+
+    import rails_amd
+
+    monkeypatch.setenv("RAILS_DTRSM_LOOPS", str(loops))
+    lib = rails_amd.load()
+    dp = C.POINTER(C.c_double)
+    g = np.random.default_rng(3)
+    m, n = 7, 5
+    for side in (b"L", b"R"):
+        na = m if side == b"L" else n
+        for uplo in (b"L", b"U"):
+            for trans in (b"N", b"T"):
+                for diag in (b"N", b"U"):
+                    A = g.uniform(-1, 1, (na, na)) + 4 * np.eye(na)
+                    Af = np.asfortranarray(np.pad(A, ((0, 3), (0, 0))))          # lda = na + 3; the other triangle holds junk
+                    Bm = g.uniform(-1, 1, (m, n))
+                    Bf = np.asfortranarray(np.pad(Bm, ((0, 2), (0, 0))))         # ldb = m + 2
+                    lib.rails_dtrsm(side, uplo, trans, diag, m, n, 0.5, Af.ctypes.data_as(dp), na + 3, Bf.ctypes.data_as(dp), m + 2)
+                    Tm = np.tril(A) if uplo == b"L" else np.triu(A)
+                    if diag == b"U":
+                        np.fill_diagonal(Tm, 1.0)
+                    op = Tm.T if trans == b"T" else Tm
+                    want = 0.5 * (np.linalg.solve(op, Bm) if side == b"L" else np.linalg.solve(op.T, Bm.T).T)
+                    np.testing.assert_allclose(Bf[:m], want, rtol=0, atol=1e-13, err_msg=str((side, uplo, trans, diag)))
+                    assert np.array_equal(Bf[m:], np.zeros((2, n)))
+
+
 def test_host_pivoted_cholesky_reveals_rank():
     # rails_dpstrf (projected-space residual Lanczos, rails/HipSolverOps.hpp): P'SP = R'R on a rank-deficient Gram matrix
     import rails_amd
