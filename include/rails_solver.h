@@ -60,7 +60,9 @@ int rails_solver_profile(rails_solver *s, char *buf, int cap);
 const char *rails_solver_backend_stats(rails_solver *s);
 
 /* ||A X + X A' + B B'||_F / ||B B'||_F for X = V T V' evaluated on the device without forming X
- * (uses R = [AV V B] G [AV V B]'; test / reporting helper) */
+ * (uses R = [AV V B] G [AV V B]'; test / reporting helper).  The norm comes out of a trace of Gram products, i.e. as the
+ * square root of a difference of O(||X||^2 ||A||^2) terms: it bottoms out near 1e-8 relative.  Below that use products with R
+ * itself (tests/test_gpu_fullsize.py does a power iteration on R). */
 int rails_solver_relative_residual(rails_solver *s, double *rel);
 
 #ifdef __cplusplus

@@ -92,6 +92,7 @@ class Solver:
         return json.loads(buf.value.decode())
 
     def relative_residual(self):
+        """||A X M' + M X A' + B B'||_F / ||B B'||_F from Gram products on the device; bottoms out near 1e-8 (include/rails_solver.h)"""
         rel = C.c_double(0.0)
         check(self.lib.rails_solver_relative_residual(self.h, C.byref(rel)), "rails_solver_relative_residual")
         return rel.value
