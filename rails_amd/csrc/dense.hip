@@ -31,7 +31,7 @@ __device__ __forceinline__ v4f64 mfma_f64(double a, double b, v4f64 c)
 // grid.x = row slabs, grid.y = tile groups (gi over X column tiles, gj over Y column tiles).
 // Each of the 4 waves accumulates TI x TJ output tiles over its share of the slab's rows.
 template <int TI, int TJ>
-__global__ __launch_bounds__(256) void k_gram(const double *__restrict__ X, int ldx, int a, const double *__restrict__ Y, int ldy,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_gram(const double *__restrict__ X, int ldx, int a, const double *__restrict__ Y, int ldy,
                                               int b, int64_t m, int64_t rows_per_slab, int ngj, double *__restrict__ partial)
 {
     __shared__ double red[TI * TJ * 256];
@@ -56,20 +56,34 @@ __global__ __launch_bounds__(256) void k_gram(const double *__restrict__ X, int 
 #pragma unroll
     for (int j = 0; j < TJ; ++j) yok[j] = (ycol0 + 16 * j + li) < b;
 
-    for (int64_t r = r_begin + 4 * wave; r < r_end; r += 16) {
+    // software pipeline: the operands of the next 4-row step are in flight while the MFMAs of this one run (one step's loads per
+    // wave do not cover the HBM latency at 3 waves per SIMD: the Gram at 17 columns ran at 37 % of the HBM rate without it)
+    auto fetch = [&](int64_t r, double *xa, double *yb) {
         const int64_t row = r + kk;
         const bool rok = row < r_end;
-        double xa[TI], yb[TJ];
         const double *xr = X + row * ldx + xcol0 + li;
         const double *yr = Y + row * ldy + ycol0 + li;
 #pragma unroll
         for (int i = 0; i < TI; ++i) xa[i] = (rok && xok[i]) ? xr[16 * i] : 0.0;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) yb[j] = (rok && yok[j]) ? yr[16 * j] : 0.0;
+    };
+    double xa[TI], yb[TJ], xn[TI], yn[TJ];
+    int64_t r = r_begin + 4 * wave;
+    if (r < r_end) fetch(r, xa, yb);
+    for (; r < r_end; r += 16) {
+        const bool more = r + 16 < r_end;
+        if (more) fetch(r + 16, xn, yn);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) acc[i][j] = mfma_f64(xa[i], yb[j], acc[i][j]);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) xa[i] = xn[i];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) yb[j] = yn[j];
+        }
     }
 
     // cross-wave reduction in a fixed order (wave 0 += wave 1, 2, 3)
@@ -106,6 +120,73 @@ __global__ __launch_bounds__(256) void k_gram(const double *__restrict__ X, int 
                     if (ci < a && cj < b) P[ci + (int64_t)cj * a] = acc[i][j][v];
                 }
     }
+}
+
+// Wide-X / narrow-Y form (the projections [P | X]' X of the coordinate-space back end: a = dim + w >> b = w <= 32): the four waves
+// of a block take four ADJACENT 64-column strips of X for the SAME rows, so a block reads whole 2 KiB row segments (the row-split
+// form above reads 512 B per row and block; measured 3.0 -> see profiles/r01_kernels.md) and Y's few columns once; every wave owns
+// its output tiles, so there is no cross-wave reduction.  Two 4-row steps are in flight per wave.
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_gram_cols(const double *__restrict__ X, int ldx, int a,
+                                                                                             const double *__restrict__ Y, int ldy, int b, int64_t m,
+                                                                                             int64_t rows_per_slab, double *__restrict__ partial)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int xcol0 = ((int)blockIdx.y * 4 + wave) * TI * 16;
+    if (xcol0 >= a) return; // wave-uniform; no barrier below
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_slab;
+    int64_t r_end = r_begin + rows_per_slab;
+    if (r_end > m) r_end = m;
+
+    v4f64 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    bool xok[TI], yok[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) xok[i] = (xcol0 + 16 * i + li) < a;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) yok[j] = (16 * j + li) < b;
+
+    auto fetch = [&](int64_t r, double *xa, double *yb) {
+        const int64_t row = r + kk;
+        const bool rok = row < r_end;
+        const double *xr = X + row * ldx + xcol0 + li;
+        const double *yr = Y + row * ldy + li;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) xa[i] = (rok && xok[i]) ? xr[16 * i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) yb[j] = (rok && yok[j]) ? yr[16 * j] : 0.0;
+    };
+    double xa[TI], ya[TJ], xb[TI], yb[TJ];
+    fetch(r_begin, xa, ya);
+    fetch(r_begin + 4, xb, yb);
+    for (int64_t r = r_begin; r < r_end; r += 8) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = mfma_f64(xa[i], ya[j], acc[i][j]);
+        fetch(r + 8, xa, ya); // rows past the slab come back as zeros
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = mfma_f64(xb[i], yb[j], acc[i][j]);
+        fetch(r + 12, xb, yb);
+    }
+    double *P = partial + (int64_t)blockIdx.x * a * b;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                int ci = xcol0 + 16 * i + kk + 4 * v; // D row  -> X column
+                int cj = 16 * j + li;                 // D col  -> Y column
+                if (ci < a && cj < b) P[ci + (int64_t)cj * a] = acc[i][j][v];
+            }
 }
 
 // out[e] = sum_t partial[t][e] in a fixed order: 16 interleaved strands per element, then the strands 0..15
@@ -237,7 +318,42 @@ int rails_gram_dev(rails_ctx *c, const double *X, int ldx, const double *Y, int 
     RAILS_TRY(rails_ws_reserve(c, (size_t)nslab * n * sizeof(double)));
     if (b <= 16 && a <= 16)
         launch_gram<1, 1>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
-    else if (b <= 16)
+    else if (b <= 32 && a >= 128) {
+        static const int cols_form = getenv("RAILS_GRAM_COLS") ? atoi(getenv("RAILS_GRAM_COLS")) : 1;
+        if (cols_form) {
+            // tiles of 16 X-columns per wave: the choice that leaves the fewest idle tile slots in blocks of four waves
+            const int ntiles = (a + 15) / 16;
+            const int cand2[3] = {3, 4, 5}, cand1[3] = {4, 6, 8};
+            const int *cand = b <= 16 ? cand1 : cand2;
+            int best = cand[1], best_cost = 1 << 30;
+            for (int q = 0; q < 3; ++q) {
+                int ti = cand[q], strips = (ntiles + ti - 1) / ti, cost = (strips + 3) / 4 * 4 * ti;
+                if (cost < best_cost) best = ti, best_cost = cost;
+            }
+            const dim3 grid((unsigned)nslab, (unsigned)(((ntiles + best - 1) / best + 3) / 4));
+#define RAILS_GRAM_COLS_CASE(TI, TJ)                                                                                                     \
+    hipLaunchKernelGGL((k_gram_cols<TI, TJ>), grid, dim3(256), 0, c->stream, X, ldx, a, Y, ldy, b, m, rps, c->ws)
+            if (b <= 16) {
+                if (best == 4)
+                    RAILS_GRAM_COLS_CASE(4, 1);
+                else if (best == 6)
+                    RAILS_GRAM_COLS_CASE(6, 1);
+                else
+                    RAILS_GRAM_COLS_CASE(8, 1);
+            } else {
+                if (best == 3)
+                    RAILS_GRAM_COLS_CASE(3, 2);
+                else if (best == 4)
+                    RAILS_GRAM_COLS_CASE(4, 2);
+                else
+                    RAILS_GRAM_COLS_CASE(5, 2);
+            }
+#undef RAILS_GRAM_COLS_CASE
+        } else if (b <= 16)
+            launch_gram<8, 1>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
+        else
+            launch_gram<4, 2>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
+    } else if (b <= 16)
         launch_gram<8, 1>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
     else if (a <= 16)
         launch_gram<1, 8>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
