@@ -357,6 +357,8 @@ int rails_gram_dev(rails_ctx *c, const double *X, int ldx, const double *Y, int 
         launch_gram<8, 1>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
     else if (a <= 16)
         launch_gram<1, 8>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
+    else if (a <= 32 && b <= 32) // the block's own 17 x 17 Gram matrices of CholQR2
+        launch_gram<2, 2>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
     else if (b <= 32)
         launch_gram<4, 2>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
     else if (a <= 32)

@@ -51,6 +51,10 @@ def main():
         print(json.dumps({"case": name, "ms": round(ms, 4), "GB": round(nbytes / 1e9, 3), "GBs": round(nbytes / ms / 1e6, 1), "frac_hbm_8TBs": round(nbytes / ms / 8e9, 3),
                           "TFLOPs_useful": round(flops / ms / 1e9, 2)}), flush=True)
 
+    out = np.zeros((w, w), order="F")
+    timed("CholQR Gram %d x %d" % (w, w), lambda: lib.rails_gram(ctx.h, Pn.panel.h, 0, w, Pn.panel.h, 0, w, _p(out), w), w * m * 8, 2.0 * m * w * w)
+    Rm = np.asfortranarray(np.triu(rng.uniform(0.5, 1.0, (w, w))))
+    timed("CholQR update k=%d r=%d in place" % (w, w), lambda: lib.rails_panel_gemm(ctx.h, 1.0, Pn.panel.h, 0, w, _p(Rm), w, w, 0.0, Pn.panel.h, 0), 2 * w * m * 8, 2.0 * m * w * w)
     for dim in dims:
         out = np.zeros((dim + w, w), order="F")
         timed("gram (%d+%d) x %d" % (dim, w, w), lambda: lib.rails_gram(ctx.h, Pn.panel.h, 0, dim + w, Pn.panel.h, dim, w, _p(out), dim + w),
