@@ -166,41 +166,70 @@ public:
         const int dw = dim + w;
         std::vector<double> CG((size_t)dw * w), G0((size_t)w * w), G((size_t)w * w);
         bool have_G = false;
+        int w2 = w;                // columns [0, w2) take part in the second round
+        std::vector<double> C1t;   // first-round coefficients of the columns [w2, w) (for their Gram entries, see below)
         for (int round = 0; round < 2; ++round) {
-            if (!hip_ok(rails_gram(ctx, pp, 0, dw, pp, dim, w, CG.data(), dw), "rails_gram")) return fail();
-            for (int j = 0; j < w; ++j)
-                for (int i = 0; i < w; ++i) (round == 0 ? G0 : G)[i + (size_t)j * w] = CG[(dim + i) + (size_t)j * dw];
+            const int wr = round == 0 ? w : w2;
+            if (!hip_ok(rails_gram(ctx, pp, 0, dw, pp, dim, wr, CG.data(), dw), "rails_gram")) return fail();
+            if (round == 0) {
+                for (int j = 0; j < w; ++j)
+                    for (int i = 0; i < w; ++i) G0[i + (size_t)j * w] = CG[(dim + i) + (size_t)j * dw];
+            }
             if (dim == 0) {
                 G = G0;
                 have_G = true;
                 break;
             }
-            std::vector<double> c2(w, 0.0); // squared length of what this round finds along P, per column
-            for (int j = 0; j < w; ++j)
+            std::vector<double> c2(wr, 0.0); // squared length of what this round finds along P, per column
+            for (int j = 0; j < wr; ++j)
                 for (int i = 0; i < dim; ++i) c2[j] += CG[i + (size_t)j * dw] * CG[i + (size_t)j * dw];
-            if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, CG.data(), dw, w, 1.0, pp, dim), "rails_panel_gemm")) return fail();
-            double worst = 1.0; // smallest fraction of a column's squared norm that survives the projection
-            for (int j = 0; j < w; ++j) {
+            if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, CG.data(), dw, wr, 1.0, pp, dim), "rails_panel_gemm")) return fail();
+            for (int j = 0; j < wr; ++j)
                 for (int i = 0; i < dim; ++i) coef[i + (size_t)j * ld] += CG[i + (size_t)j * dw];
-                const double g = (round == 0 ? G0 : G)[j + (size_t)j * w];
-                worst = std::min(worst, g > 0.0 ? 1.0 - c2[j] / g : 0.0);
-            }
             if (round == 0) {
                 // "twice is enough" (Kahan / Parlett; the DGKS rule): one projection leaves a component (eps + delta) * ||x|| / ||x'||
-                // along P, delta = ||P'P - I||.  Where at least half of every column's squared norm survives that factor is <= sqrt(2)
+                // along P, delta = ||P'P - I||.  Where at least half of a column's squared norm survives that factor is <= sqrt(2)
                 // and a second projection has nothing to repair.  A looser rule is unstable over long runs: the defect of each new
                 // basis column is the old delta times ||x|| / ||x'||, and chains of small survivals compound it (measured with 1 %: V'V - I
                 // of 1e-14, 2e-12, 6e-7, 0.9 after 50, 100, 200, 400 trips of a stagnating solve).
-                if (trace) std::cerr << "absorb: dim " << dim << " w " << w << " first round: smallest survival " << worst << std::endl;
-                if (worst > reorth_survival) break;
+                // The rule is applied per column; the second round runs on the leading columns up to the last one that needs it (the
+                // prefetched random vector at the end of an A*W block never does: one MFMA tile of 16 columns instead of two).
+                double worst = 1.0; // smallest fraction of a column's squared norm that survives the projection
+                w2 = 0;
+                for (int j = 0; j < w; ++j) {
+                    const double g = G0[j + (size_t)j * w];
+                    const double surv = g > 0.0 ? 1.0 - c2[j] / g : 0.0;
+                    worst = std::min(worst, surv);
+                    if (!(surv > reorth_survival)) w2 = j + 1;
+                }
+                if (trace) std::cerr << "absorb: dim " << dim << " w " << w << " first round: smallest survival " << worst << ", second round on " << w2 << " columns" << std::endl;
+                if (w2 == 0) break;
                 n_second_round++;
+                if (w2 < w) { // keep what the Gram entries of the untouched columns need
+                    C1t.assign((size_t)dim * (w - w2), 0.0);
+                    for (int j = w2; j < w; ++j) memcpy(C1t.data() + (size_t)(j - w2) * dim, CG.data() + (size_t)j * dw, sizeof(double) * dim);
+                }
             } else {
-                // after the second round the block's Gram matrix is the one just measured minus the (tiny) second correction
-                for (int j = 0; j < w; ++j)
+                // The block's Gram matrix after the second round.  Columns i, j < w2: the one just measured minus the (tiny) second
+                // correction.  One of them >= w2: as measured (the correction term is the product of two rounding-level quantities).
+                // Both >= w2 (projected once, more than half survived): the first Gram matrix minus the first correction.
+                for (int j = 0; j < w2; ++j)
                     for (int i = 0; i < w; ++i) {
-                        double s2 = 0.0;
-                        for (int l = 0; l < dim; ++l) s2 += CG[l + (size_t)i * dw] * CG[l + (size_t)j * dw];
-                        G[i + (size_t)j * w] -= s2;
+                        double v = CG[(dim + i) + (size_t)j * dw];
+                        if (i < w2) {
+                            double s2 = 0.0;
+                            for (int l = 0; l < dim; ++l) s2 += CG[l + (size_t)i * dw] * CG[l + (size_t)j * dw];
+                            v -= s2;
+                        }
+                        G[i + (size_t)j * w] = v;
+                        G[j + (size_t)i * w] = v;
+                    }
+                for (int j = w2; j < w; ++j)
+                    for (int i = w2; i < w; ++i) {
+                        double s1 = 0.0;
+                        const double *ci = C1t.data() + (size_t)(i - w2) * dim, *cj = C1t.data() + (size_t)(j - w2) * dim;
+                        for (int l = 0; l < dim; ++l) s1 += ci[l] * cj[l];
+                        G[i + (size_t)j * w] = G0[i + (size_t)j * w] - s1;
                     }
                 have_G = true;
             }
