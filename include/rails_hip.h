@@ -211,9 +211,18 @@ int rails_timer_stop(rails_ctx *ctx, double *ms);
 /* src/SlicotWrapper.hpp:14-16.  Only (dico,job,fact) = ('C','X','N') is supported (the only use,
  * src/LyapunovSolver.hpp:357).  trans='T' solves A*X + X*A^T = scale*C, trans='N' A^T*X + X*A.
  * SLICOT itself is not available: Bartels-Stewart on dgees + dtrsyl; info = n+1 when the
- * triangular solve had to perturb (SLICOT's convention). */
+ * triangular solve had to perturb (SLICOT's convention).  Two faster routes to the same X are tried first
+ * where they apply, each checked before it is accepted: the eigen-decomposition for a symmetric A, and a
+ * squared Smith iteration (level-3 BLAS, residual-verified to the level Bartels-Stewart reaches) for a
+ * nonsymmetric A whose spectrum is clustered.  A holds its Schur form afterwards only
+ * on the Bartels-Stewart route. */
 void rails_sb03md(char dico, char job, char fact, char trans, int n, double *A, int lda, double *X, int ldx,
                   double *scale, int *info);
+/* how many calls of this process took the squared-Smith route and the Bartels-Stewart route (diagnostics) */
+void rails_sb03md_counts(long *smith, long *schur);
+/* after an attempt of the squared-Smith route that did not apply, the calling thread skips the attempt for the next 30 calls;
+ * this sets that counter (0: try again at the next call) */
+void rails_sb03md_set_pause(int calls);
 /* src/LapackWrapper.hpp:21-22 */
 void rails_dsyev(char jobz, char uplo, int n, double *a, int lda, double *w, int *info);
 /* src/LapackWrapper.hpp:18-19 */

@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,8 @@ typedef void (*lp_dgemm)(const char *, const char *, const int *, const int *, c
                          const int *, const double *, const int *, const double *, double *, const int *);
 typedef void (*lp_dtrsm)(const char *, const char *, const char *, const char *, const int *, const int *, const double *, const double *,
                          const int *, double *, const int *);
+typedef void (*lp_dgetrf)(const int *, const int *, double *, const int *, int *, int *);
+typedef void (*lp_dgetrs)(const char *, const int *, const int *, const double *, const int *, const int *, double *, const int *, int *);
 }
 
 struct HostLapack {
@@ -58,6 +61,8 @@ struct HostLapack {
     lp_dorgqr dorgqr = nullptr;
     lp_dgemm dgemm = nullptr;
     lp_dtrsm dtrsm = nullptr; // optional: the generalized projected solve falls back to loops
+    lp_dgetrf dgetrf = nullptr; // optional: the squared-Smith fast path of rails_sb03md
+    lp_dgetrs dgetrs = nullptr;
 } g_lp;
 std::mutex g_lp_mutex;
 
@@ -88,6 +93,8 @@ bool try_open(const std::string &path)
     L.dpotrf = (lp_dpotrf)lookup(h, "dpotrf_");
     L.dgemm = (lp_dgemm)lookup(h, "dgemm_");
     L.dtrsm = (lp_dtrsm)lookup(h, "dtrsm_");
+    L.dgetrf = (lp_dgetrf)lookup(h, "dgetrf_");
+    L.dgetrs = (lp_dgetrs)lookup(h, "dgetrs_");
     L.dpstrf = (lp_dpstrf)lookup(h, "dpstrf_");
     L.dgeqp3 = (lp_dgeqp3)lookup(h, "dgeqp3_");
     L.dorgqr = (lp_dorgqr)lookup(h, "dorgqr_");
@@ -360,6 +367,100 @@ extern "C" void rails_range_basis(int m, int n, double *a, int lda, double tol, 
     g_lp.dorgqr(&m, &r, &r, q, &ldq, tau.data(), work.data(), &lwork, info);
 }
 
+static int &sb03md_smith_pause()
+{
+    static thread_local int pause = 0; // calls of this thread that skip the Smith attempt after one that did not apply
+    return pause;
+}
+extern "C" void rails_sb03md_set_pause(int calls) { sb03md_smith_pause() = calls > 0 ? calls : 0; }
+static std::atomic<long> g_sb03md_smith{0}, g_sb03md_schur{0};
+extern "C" void rails_sb03md_counts(long *smith, long *schur)
+{
+    if (smith) *smith = g_sb03md_smith.load();
+    if (schur) *schur = g_sb03md_schur.load();
+}
+
+// Squared Smith iteration for M X + X M' = C (M stable, n >= 32): with p > 0, S = M - p I,
+//     X = Md X Md' + Cd,   Md = S^-1 (M + p I) = I + 2 p S^-1,   Cd = -2 p S^-1 C S^-T,
+// and X = sum_j Md^j Cd Md'^j is summed by squaring: Y <- Y + Ak Y Ak', Ak <- Ak^2.  With p = -trace(M)/n the spectral radius of
+// Md is small whenever the spectrum of M is clustered relative to its distance from the imaginary axis -- the projections V'AV
+// of diagonally dominant operators (the benchmark's: rho ~ 0.1-0.25, 4-6 squarings).  All level-3 BLAS: ~40 n^3 flops at GEMM
+// speed against the ~25 n^3 flops of the Hessenberg QR sweeps at a fifth of it (2.5 vs 6.9 ms at n = 160).  The result is
+// VERIFIED -- ||M X + X M' - C||_F <= 2e-15 (2 ||M|| ||X|| + ||C||), the level Bartels-Stewart reaches -- and anything else
+// (slow convergence, an unstable M, a failed check) returns false: the caller then runs Bartels-Stewart as before.
+static bool smith_lyapunov(bool tr, int n, const double *A, int lda, double *X, int ldx)
+{
+    if (!g_lp.dgetrf || !g_lp.dgetrs) return false;
+    const size_t nn = (size_t)n * n;
+    std::vector<double> M(nn), S(nn), Ak(nn), Y(nn), T1(nn), T2(nn), C(nn);
+    double trace = 0.0;
+    for (int j = 0; j < n; ++j) {
+        for (int i = 0; i < n; ++i) {
+            M[i + (size_t)j * n] = tr ? A[i + (size_t)j * lda] : A[j + (size_t)i * lda];
+            C[i + (size_t)j * n] = 0.5 * (X[i + (size_t)j * ldx] + X[j + (size_t)i * ldx]);
+        }
+        trace += A[j + (size_t)j * lda];
+    }
+    const double p = -trace / n;
+    if (!(p > 0.0) || !std::isfinite(p)) return false;
+    S = M;
+    for (int j = 0; j < n; ++j) S[j + (size_t)j * n] -= p;
+    std::vector<int> ipiv(n);
+    int info = 0;
+    g_lp.dgetrf(&n, &n, S.data(), &n, ipiv.data(), &info);
+    if (info != 0) return false;
+    std::fill(Ak.begin(), Ak.end(), 0.0);
+    for (int j = 0; j < n; ++j) Ak[j + (size_t)j * n] = 1.0;
+    const char N = 'N';
+    g_lp.dgetrs(&N, &n, &n, S.data(), &n, ipiv.data(), Ak.data(), &n, &info); // Ak = S^-1
+    if (info != 0) return false;
+    // Y0 = Cd = -2p S^-1 C S^-T
+    gemm('N', 'N', n, n, n, Ak.data(), n, C.data(), n, T1.data(), n);
+    gemm('N', 'T', n, n, n, T1.data(), n, Ak.data(), n, Y.data(), n);
+    for (size_t q = 0; q < nn; ++q) Y[q] *= -2.0 * p;
+    for (size_t q = 0; q < nn; ++q) Ak[q] *= 2.0 * p; // Ak = Md = I + 2p S^-1
+    for (int j = 0; j < n; ++j) Ak[j + (size_t)j * n] += 1.0;
+    auto fro = [&](std::vector<double> const &Z) {
+        double s2 = 0.0;
+        for (size_t q = 0; q < nn; ++q) s2 += Z[q] * Z[q];
+        return std::sqrt(s2);
+    };
+    bool converged = false;
+    for (int k = 0; k < 10; ++k) {
+        gemm('N', 'N', n, n, n, Ak.data(), n, Y.data(), n, T1.data(), n);
+        gemm('N', 'T', n, n, n, T1.data(), n, Ak.data(), n, T2.data(), n);
+        const double inc = fro(T2), ny = fro(Y);
+        if (!std::isfinite(inc) || inc > 10.0 * ny) return false; // not a contraction: M is not stable (enough)
+        for (size_t q = 0; q < nn; ++q) Y[q] += T2[q];
+        if (inc <= 1e-16 * ny) {
+            converged = true;
+            break;
+        }
+        if (k >= 5 && inc > 1e-2 * ny) return false; // the ratio squares per step: would need more squarings than Bartels-Stewart costs
+        gemm('N', 'N', n, n, n, Ak.data(), n, Ak.data(), n, T1.data(), n);
+        Ak.swap(T1);
+    }
+    if (!converged) return false;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < j; ++i) {
+            const double v = 0.5 * (Y[i + (size_t)j * n] + Y[j + (size_t)i * n]);
+            Y[i + (size_t)j * n] = v;
+            Y[j + (size_t)i * n] = v;
+        }
+    // verification: R = M Y + Y M' - C
+    gemm('N', 'N', n, n, n, M.data(), n, Y.data(), n, T1.data(), n);
+    double r2 = 0.0;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            const double r = T1[i + (size_t)j * n] + T1[j + (size_t)i * n] - C[i + (size_t)j * n]; // Y M' = (M Y)' for symmetric Y
+            r2 += r * r;
+        }
+    if (!(std::sqrt(r2) <= 2e-15 * (2.0 * fro(M) * fro(Y) + fro(C)))) return false;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) X[i + (size_t)j * ldx] = Y[i + (size_t)j * n];
+    return true;
+}
+
 // Continuous-time Lyapunov equation, SB03MD('C','X','N',trans):
 //   trans = 'T':  A X + X A^T = scale * C        trans = 'N':  A^T X + X A = scale * C
 // C symmetric, X overwrites C.  A is overwritten by its real Schur form (as SLICOT does with FACT='N').
@@ -449,6 +550,25 @@ extern "C" void rails_sb03md(char dico, char job, char fact, char trans, int n, 
             // eigen-solver trouble or lambda_i + lambda_j = 0: let the general path deal with it
         }
     }
+    // Nonsymmetric A: the squared Smith iteration first (level-3 BLAS, verified; RAILS_SB03MD_SMITH=0 disables).  Where it does not
+    // apply it says so after a few products; a solver whose projected matrices are of that kind stops asking for a while.  A keeps
+    // its values on this path (SLICOT would leave the Schur form; no caller of this library reads A afterwards).
+    static const bool use_smith = [] {
+        const char *e = getenv("RAILS_SB03MD_SMITH");
+        return e ? atoi(e) != 0 : true;
+    }();
+    int &smith_pause = sb03md_smith_pause();
+    if (use_smith && n >= 32) {
+        if (smith_pause > 0)
+            --smith_pause;
+        else if (smith_lyapunov(tr, n, A, lda, X, ldx)) {
+            g_sb03md_smith++;
+            *scale = 1.0;
+            return;
+        } else
+            smith_pause = 30;
+    }
+    g_sb03md_schur++;
     std::vector<double> U((size_t)n * n), wr(n), wi(n), F((size_t)n * n), W((size_t)n * n);
     int sdim = 0, lwork = -1, linfo = 0;
     double wq = 0.0;

@@ -132,6 +132,62 @@ def test_host_dsyev_and_dsteqr():
     np.testing.assert_allclose(dd, w, atol=1e-13)
 
 
+def test_host_sb03md_smith_route_is_verified_and_falls_back():
+    """rails_sb03md on nonsymmetric matrices of 32 rows and more tries the squared Smith iteration first (level-3 BLAS, residual-verified)
+    and runs Bartels-Stewart where that does not apply: both routes against scipy's Bartels-Stewart, both `trans` forms"""
+    import scipy.linalg as sl
+
+    import rails_amd
+
+    lib = rails_amd.load()
+    dp = C.POINTER(C.c_double)
+
+    def counts():
+        a, b = C.c_long(0), C.c_long(0)
+        lib.rails_sb03md_counts(C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def solve(A, Cm, trans):
+        n = A.shape[0]
+        Ap, X = np.asfortranarray(A.copy()), np.asfortranarray(Cm.copy())
+        scale, info = C.c_double(0), C.c_int(0)
+        lib.rails_sb03md(b"C", b"X", b"N", trans, n, Ap.ctypes.data_as(dp), n, X.ctypes.data_as(dp), n, C.byref(scale), C.byref(info))
+        assert info.value == 0 and scale.value == 1.0
+        return X
+
+    g = np.random.default_rng(7)
+    # (a) clustered spectrum (the projection of a diagonally dominant operator): the Smith route, to rounding
+    for n in (32, 75, 160):
+        A = -14.0 * np.eye(n) + 0.6 * g.uniform(0, 1, (n, n)) * (g.uniform(size=(n, n)) < 27.0 / n)
+        Bm = g.standard_normal((n, 5))
+        Cm = -(Bm @ Bm.T)
+        for trans in (b"T", b"N"):
+            lib.rails_sb03md_set_pause(0)
+            s0, b0 = counts()
+            X = solve(A, Cm, trans)
+            assert counts() == (s0 + 1, b0)
+            Mm = A if trans == b"T" else A.T
+            Xref = sl.solve_continuous_lyapunov(Mm, Cm)
+            assert np.linalg.norm(X - Xref) <= 5e-14 * np.linalg.norm(Xref)
+            assert np.linalg.norm(Mm @ X + X @ Mm.T - Cm) <= 1e-14 * (2 * np.linalg.norm(Mm) * np.linalg.norm(X) + np.linalg.norm(Cm))
+            assert np.array_equal(X, X.T)
+    # (b) a spectrum spread over four decades: Smith gives up after a few products, Bartels-Stewart answers; (c) an unstable matrix
+    n = 96
+    spread = -np.diag(np.logspace(-2, 2, n)) + 0.05 * g.standard_normal((n, n))
+    unstable = spread.copy()
+    unstable[0, 0] = 3.0
+    for A in (spread, unstable):
+        Bm = g.standard_normal((n, 3))
+        Cm = -(Bm @ Bm.T)
+        lib.rails_sb03md_set_pause(0)
+        s0, b0 = counts()
+        X = solve(A, Cm, b"T")
+        s1, b1 = counts()
+        assert s1 == s0 and b1 == b0 + 1
+        Xref = sl.solve_continuous_lyapunov(A, Cm)
+        assert np.linalg.norm(X - Xref) <= 1e-9 * np.linalg.norm(Xref)  # conditioning of these problems, same algorithm on both sides
+
+
 @pytest.mark.parametrize("loops", [0, 1])
 def test_host_dtrsm_all_forms(loops, monkeypatch):
     """rails_dtrsm (the six triangular solves of the generalized projected solve): BLAS path and the loop fallback, every
