@@ -83,8 +83,14 @@ def make_allreduce(on_device=True, group=None, host_staged=False):
     tensors (rehearsals of the multi-process path on a backend without device collectives, i.e. gloo)."""
     import torch.distributed as dist
 
+    wrapped = {}  # (ptr, n) -> tensor view: the library re-uses one small device buffer, wrapping it costs more than the collective
+
     def allreduce(ptr, n, stream):
-        t = wrap_buffer(ptr, n, on_device)
+        t = wrapped.get((ptr, n))
+        if t is None:
+            if len(wrapped) > 64:
+                wrapped.clear()
+            t = wrapped[(ptr, n)] = wrap_buffer(ptr, n, on_device)
         if on_device and host_staged:
             h = t.cpu()  # synchronises with the current stream
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
