@@ -238,7 +238,10 @@ def main():
     solver.set_option("subspace", args.subspace)
     marks = {}
 
+    stamps = []  # host time at the end of every trip (diagnostics: one slow trip shows up here)
+
     def on_trip(trip):
+        stamps.append(time.perf_counter())
         if trip == W or trip == W + K:
             torch.cuda.synchronize()
             if dist is not None:
@@ -247,7 +250,15 @@ def main():
             marks[trip] = time.perf_counter()
 
     solver.set_trip_callback(on_trip)
-    code, _, _ = solver.solve(fetch=False)
+    cpu_at_start = os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1
+    import gc
+
+    gc.collect()
+    gc.disable()  # the trip callback is the only Python in the loop: no collector pause inside the timed region
+    try:
+        code, _, _ = solver.solve(fetch=False)
+    finally:
+        gc.enable()
     assert solver.trips() == W + K, "solver stopped after %d trips (code %d)" % (solver.trips(), code)
     elapsed = marks[W + K] - marks[W]
     if dist is not None:
@@ -257,6 +268,10 @@ def main():
     its = K / elapsed
     hist = solver.history()
     log("[rank %d] host sections (s, whole solve incl. warm-up): %s" % (rank, json.dumps(solver.profile())))
+    if len(stamps) > W + 2:
+        dts = np.diff(np.array(stamps))[W:]
+        log("[rank %d] timed trips: median %.2f ms, slowest %.2f ms (trip %d); host thread on cpu %d -> %d" % (
+            rank, 1e3 * float(np.median(dts)), 1e3 * float(dts.max()), W + 1 + int(dts.argmax()), cpu_at_start, os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1))
     log("[rank %d] counters: %s %s" % (rank, json.dumps(ctx.stats()), json.dumps(solver.backend_stats())))
     log("[rank %d] %d trips in %.3fs -> %.2f it/s; Lanczos estimates %.3e -> %.3e; V.N()=%d" % (rank, K, elapsed, its, hist[0], hist[-1], solver.k))
 

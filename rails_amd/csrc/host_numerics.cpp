@@ -372,7 +372,12 @@ static int &sb03md_smith_pause()
     static thread_local int pause = 0; // calls of this thread that skip the Smith attempt after one that did not apply
     return pause;
 }
-extern "C" void rails_sb03md_set_pause(int calls) { sb03md_smith_pause() = calls > 0 ? calls : 0; }
+static int &sb03md_factored_pause()
+{
+    static thread_local int pause = 0; // the factored (ADI) form is tried first; where it gives up it rests on its own count
+    return pause;
+}
+extern "C" void rails_sb03md_set_pause(int calls) { sb03md_smith_pause() = sb03md_factored_pause() = calls > 0 ? calls : 0; }
 static std::atomic<long> g_sb03md_smith{0}, g_sb03md_schur{0};
 extern "C" void rails_sb03md_counts(long *smith, long *schur)
 {
@@ -461,14 +466,19 @@ static bool smith_lyapunov(bool tr, int n, const double *A, int lda, double *X, 
     return true;
 }
 
-// The same iteration in factored form for a right-hand side of low rank -- the solver's is +-(V'B)(V'B)' with p = 16 columns:
-// C = sign * F F' (pivoted Cholesky, rank r), X = -sign * sum_j Zj Zj', Z0 = sqrt(2p) S^-1 F, Zj = Md Zj-1 = Zj-1 + 2p S^-1 Zj-1.
-// No squaring and no n x n products inside the iteration: one LU factorisation, one solve with r right-hand sides per term, then
-// X = Z Z' and the residual check -- ~6 n^3 flops at n = 200, r = 16 instead of ~30 n^3 for the dense form (0.8 vs 2.2 ms).  All
-// terms are positive semi-definite, so nothing cancels.  Same fences as above.
-static bool smith_lyapunov_lowrank(bool tr, int n, const double *A, int lda, double *X, int ldx)
+// Factored ADI for a right-hand side of low rank -- the solver's is +-(V'B)(V'B)' with p = 16 columns.  C = sign * F F' (pivoted
+// Cholesky, rank r) and, for shifts p_1, p_2, ... > 0 (Li / White's low-rank ADI),
+//     Z_1 = sqrt(2 p_1) (M - p_1 I)^-1 F,   Z_j = sqrt(p_j / p_j-1) [I + (p_j + p_j-1) (M - p_j I)^-1] Z_j-1,   X = -sign * sum_j Z_j Z_j'.
+// The shifts are L points spaced logarithmically over [a, b], the extent of M's spectrum along the real axis (a from a few inverse
+// iterations with an LU of M, b from a few power iterations), used cyclically: every mode is damped by the shifts near it, so the
+// terms shrink by a roughly constant factor per cycle however far the spectrum is spread (the squared Smith iteration above has ONE
+// shift and pays for spread spectra with squarings of n x n matrices).  Cost: L + 1 LU factorisations, one solve with r right-hand
+// sides per term, X = Z Z', the residual check -- ~12 n^3 flops at n = 200, r = 16 against ~35 n^3.  All terms are positive
+// semi-definite: nothing cancels.  Same fences: verified residual, early exit when the terms do not shrink, false = not applicable.
+static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, double *X, int ldx)
 {
     if (!g_lp.dgetrf || !g_lp.dgetrs) return false;
+    static const bool trace_lr = getenv("RAILS_SB03MD_TRACE") != nullptr;
     const size_t nn = (size_t)n * n;
     std::vector<double> C(nn), W(nn);
     double trc = 0.0, dmax = 0.0;
@@ -483,75 +493,110 @@ static bool smith_lyapunov_lowrank(bool tr, int n, const double *A, int lda, dou
     std::vector<int> piv(n);
     int rank = 0, info = 0;
     rails_dpstrf('U', n, W.data(), n, piv.data(), &rank, 1e-15 * dmax, &info);
-    static const bool trace_lr = getenv("RAILS_SB03MD_TRACE") != nullptr;
-    if (trace_lr) fprintf(stderr, "sb03md low-rank: n %d, pivoted Cholesky rank %d (info %d)\n", n, rank, info);
     if (info < 0 || rank <= 0 || rank > n / 3) return false; // not (semi-)definite of low rank: the dense form decides
     std::vector<double> F((size_t)n * rank, 0.0); // F(piv[j], i) = R(i, j)
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < rank && i <= j; ++i) F[piv[j] + (size_t)i * n] = W[i + (size_t)j * n];
-    std::vector<double> M(nn), S(nn);
-    double trace = 0.0;
-    for (int j = 0; j < n; ++j) {
+    std::vector<double> M(nn);
+    for (int j = 0; j < n; ++j)
         for (int i = 0; i < n; ++i) M[i + (size_t)j * n] = tr ? A[i + (size_t)j * lda] : A[j + (size_t)i * lda];
-        trace += A[j + (size_t)j * lda];
-    }
-    const double p = -trace / n;
-    if (!(p > 0.0) || !std::isfinite(p)) return false;
-    S = M;
-    for (int j = 0; j < n; ++j) S[j + (size_t)j * n] -= p;
-    std::vector<int> ipiv(n);
-    g_lp.dgetrf(&n, &n, S.data(), &n, ipiv.data(), &info);
-    if (info != 0) return false;
-    const int max_terms = 64, max_cols = std::max(8 * n, 64 * rank);
-    std::vector<double> Z; // n x (terms * rank)
-    Z.reserve((size_t)n * rank * 16);
-    const size_t blk = (size_t)n * rank;
-    std::vector<double> T(blk);
+    // extent of the spectrum: b ~ largest, a ~ smallest modulus (power / inverse iteration from a fixed start vector)
     const char N = 'N';
-    T = F;
-    g_lp.dgetrs(&N, &n, &rank, S.data(), &n, ipiv.data(), T.data(), &n, &info);
+    const int one = 1;
+    std::vector<double> LU0 = M;
+    std::vector<int> ip0(n);
+    g_lp.dgetrf(&n, &n, LU0.data(), &n, ip0.data(), &info);
     if (info != 0) return false;
-    const double s2p = std::sqrt(2.0 * p);
-    for (size_t q = 0; q < blk; ++q) T[q] *= s2p;
+    std::vector<double> v(n), u(n);
+    auto nrm = [&](std::vector<double> const &z) {
+        double s2 = 0.0;
+        for (int i = 0; i < n; ++i) s2 += z[i] * z[i];
+        return std::sqrt(s2);
+    };
+    for (int i = 0; i < n; ++i) v[i] = 1.0 + 0.37 * std::sin(1.0 + 2.3 * i);
+    double bmax = 0.0, amin = 0.0;
+    for (int it = 0; it < 6; ++it) {
+        const double nv = nrm(v);
+        for (int i = 0; i < n; ++i) v[i] /= nv;
+        gemm('N', 'N', n, 1, n, M.data(), n, v.data(), n, u.data(), n);
+        bmax = std::max(bmax, nrm(u));
+        v = u;
+    }
+    for (int i = 0; i < n; ++i) v[i] = 1.0 + 0.37 * std::sin(1.0 + 2.3 * i);
+    for (int it = 0; it < 6; ++it) {
+        const double nv = nrm(v);
+        for (int i = 0; i < n; ++i) v[i] /= nv;
+        g_lp.dgetrs(&N, &n, &one, LU0.data(), &n, ip0.data(), v.data(), &n, &info);
+        if (info != 0) return false;
+        amin = nrm(v); // -> 1 / |lambda|min
+    }
+    if (!(amin > 0.0) || !(bmax > 0.0) || !std::isfinite(amin) || !std::isfinite(bmax)) return false;
+    double a = 0.8 / amin, b = 1.2 * bmax;
+    if (!(a < b)) a = 0.5 * b;
+    if (b / a > 1e5) return false;
+    const int L = std::min(8, std::max(2, (int)std::ceil(0.5 * std::log2(b / a)) + 1));
+    std::vector<double> shift(L);
+    for (int i = 0; i < L; ++i) shift[i] = a * std::pow(b / a, (2.0 * i + 1.0) / (2.0 * L));
+    std::vector<std::vector<double>> LUs(L);
+    std::vector<std::vector<int>> ips(L, std::vector<int>(n));
+    for (int i = 0; i < L; ++i) {
+        LUs[i] = M;
+        for (int j = 0; j < n; ++j) LUs[i][j + (size_t)j * n] -= shift[i];
+        g_lp.dgetrf(&n, &n, LUs[i].data(), &n, ips[i].data(), &info);
+        if (info != 0) return false;
+    }
+    const size_t blk = (size_t)n * rank;
+    const int max_terms = 12 * L, max_cols = 6 * n;
+    std::vector<double> Z, T(blk);
+    Z.reserve(blk * 24);
     auto norm2 = [&](const double *z) {
         double s2 = 0.0;
         for (size_t q = 0; q < blk; ++q) s2 += z[q] * z[q];
         return s2;
     };
+    T = F;
+    g_lp.dgetrs(&N, &n, &rank, LUs[0].data(), &n, ips[0].data(), T.data(), &n, &info);
+    if (info != 0) return false;
+    {
+        const double f = std::sqrt(2.0 * shift[0]);
+        for (size_t q = 0; q < blk; ++q) T[q] *= f;
+    }
     Z.insert(Z.end(), T.begin(), T.end());
-    double total = norm2(T.data()), prev = total;
+    double total = norm2(T.data()), cycle_start = total;
     bool converged = false;
     for (int j = 1; j < max_terms; ++j) {
-        // Zj = Zj-1 + 2p S^-1 Zj-1
+        const int cur = j % L, prv = (j - 1) % L;
+        const double pj = shift[cur], pp = shift[prv];
         const double *zp = Z.data() + (size_t)(j - 1) * blk;
         std::copy(zp, zp + blk, T.begin());
-        g_lp.dgetrs(&N, &n, &rank, S.data(), &n, ipiv.data(), T.data(), &n, &info);
+        g_lp.dgetrs(&N, &n, &rank, LUs[cur].data(), &n, ips[cur].data(), T.data(), &n, &info);
         if (info != 0) return false;
-        for (size_t q = 0; q < blk; ++q) T[q] = zp[q] + 2.0 * p * T[q];
+        const double f = std::sqrt(pj / pp), g = pj + pp;
+        for (size_t q = 0; q < blk; ++q) T[q] = f * (zp[q] + g * T[q]);
         const double n2 = norm2(T.data());
-        if (!std::isfinite(n2) || n2 > 4.0 * prev) return false;          // not a contraction
-        // the terms shrink by rho^2 per step: 1e-17 takes ln(1e-17) / ln(rho^2) of them; beyond ~24 (rho > 0.45) the dense form, whose
-        // squaring reaches the same point in log2 as many steps, is the cheaper one
-        if (j >= 3 && n2 > 0.2 * prev) return false;
+        if (!std::isfinite(n2) || n2 > 1e4 * total) return false; // M is not stable
         if ((int)((size_t)(j + 1) * rank) > max_cols) return false;
         Z.insert(Z.end(), T.begin(), T.end());
         total += n2;
-        prev = n2;
         if (n2 <= 1e-17 * total) {
             converged = true;
             break;
         }
+        if (cur == L - 1) { // end of a cycle: the terms must have shrunk by a clear factor, or this is not the right tool
+            if (n2 > 0.2 * cycle_start) return false;
+            cycle_start = n2;
+        }
     }
-    if (trace_lr) fprintf(stderr, "sb03md low-rank: %d terms, converged %d\n", (int)(Z.size() / blk), (int)converged);
+    if (trace_lr) fprintf(stderr, "sb03md ADI: n %d rank %d, spectrum ~[%.3g, %.3g], %d shifts, %d terms, converged %d\n", n, rank, a, b, L, (int)(Z.size() / blk), (int)converged);
     if (!converged) return false;
     const int cols = (int)(Z.size() / n);
     std::vector<double> Y(nn);
     gemm('N', 'T', n, n, cols, Z.data(), n, Z.data(), n, Y.data(), n);
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < j; ++i) {
-            const double v = 0.5 * (Y[i + (size_t)j * n] + Y[j + (size_t)i * n]);
-            Y[i + (size_t)j * n] = v;
-            Y[j + (size_t)i * n] = v;
+            const double vv = 0.5 * (Y[i + (size_t)j * n] + Y[j + (size_t)i * n]);
+            Y[i + (size_t)j * n] = vv;
+            Y[j + (size_t)i * n] = vv;
         }
     for (size_t q = 0; q < nn; ++q) Y[q] *= -sign; // M Y + Y M' = C
     // verification with the ORIGINAL right-hand side (also covers the truncation of the pivoted Cholesky factor)
@@ -565,7 +610,7 @@ static bool smith_lyapunov_lowrank(bool tr, int n, const double *A, int lda, dou
             y2 += Y[i + (size_t)j * n] * Y[i + (size_t)j * n];
             c2 += C[i + (size_t)j * n] * C[i + (size_t)j * n];
         }
-    if (trace_lr) fprintf(stderr, "sb03md low-rank: residual %.2e of %.2e allowed\n", std::sqrt(r2), 2e-15 * (2.0 * std::sqrt(m2 * y2) + std::sqrt(c2)));
+    if (trace_lr) fprintf(stderr, "sb03md ADI: residual %.2e of %.2e allowed\n", std::sqrt(r2), 2e-15 * (2.0 * std::sqrt(m2 * y2) + std::sqrt(c2)));
     if (!(std::sqrt(r2) <= 2e-15 * (2.0 * std::sqrt(m2 * y2) + std::sqrt(c2)))) return false;
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < n; ++i) X[i + (size_t)j * ldx] = Y[i + (size_t)j * n];
@@ -669,11 +714,11 @@ extern "C" void rails_sb03md(char dico, char job, char fact, char trans, int n, 
         return e ? atoi(e) != 0 : true;
     }();
     int &smith_pause = sb03md_smith_pause();
-    static thread_local int lowrank_pause = 0; // the factored form is tried first; where it gives up it rests for 30 calls as well
+    int &lowrank_pause = sb03md_factored_pause();
     if (use_smith && n >= 32) {
         if (smith_pause > 0)
             --smith_pause;
-        else if ((lowrank_pause > 0 ? (--lowrank_pause, false) : (smith_lyapunov_lowrank(tr, n, A, lda, X, ldx) || (lowrank_pause = 30, false))) ||
+        else if ((lowrank_pause > 0 ? (--lowrank_pause, false) : (adi_lyapunov_lowrank(tr, n, A, lda, X, ldx) || (lowrank_pause = 30, false))) ||
                  smith_lyapunov(tr, n, A, lda, X, ldx)) {
             g_sb03md_smith++;
             *scale = 1.0;

@@ -171,21 +171,33 @@ def test_host_sb03md_smith_route_is_verified_and_falls_back():
             assert np.linalg.norm(X - Xref) <= 5e-14 * np.linalg.norm(Xref)
             assert np.linalg.norm(Mm @ X + X @ Mm.T - Cm) <= 1e-14 * (2 * np.linalg.norm(Mm) * np.linalg.norm(X) + np.linalg.norm(Cm))
             assert np.array_equal(X, X.T)
-    # (b) a spectrum spread over four decades: Smith gives up after a few products, Bartels-Stewart answers; (c) an unstable matrix
+    # (b) a spectrum spread over three decades, stable: the factored ADI form (several shifts) takes it; no single shift would
     n = 96
-    spread = -np.diag(np.logspace(-2, 2, n)) + 0.05 * g.standard_normal((n, n))
+    spread = -np.diag(np.logspace(-1, 2, n)) + 0.02 * g.standard_normal((n, n))
+    assert np.linalg.eigvals(spread).real.max() < 0
+    Bm = g.standard_normal((n, 3))
+    Cm = -(Bm @ Bm.T)
+    lib.rails_sb03md_set_pause(0)
+    s0, b0 = counts()
+    X = solve(spread, Cm, b"T")
+    assert counts() == (s0 + 1, b0)
+    Xref = sl.solve_continuous_lyapunov(spread, Cm)
+    assert np.linalg.norm(X - Xref) <= 1e-11 * np.linalg.norm(Xref)
+    assert np.linalg.norm(spread @ X + X @ spread.T - Cm) <= 1e-14 * (2 * np.linalg.norm(spread) * np.linalg.norm(X) + np.linalg.norm(Cm))
+    # (c) an unstable matrix, (d) a full-rank indefinite right-hand side on a spread spectrum: Bartels-Stewart answers
     unstable = spread.copy()
     unstable[0, 0] = 3.0
-    for A in (spread, unstable):
-        Bm = g.standard_normal((n, 3))
-        Cm = -(Bm @ Bm.T)
+    Cfull = g.standard_normal((n, n))
+    Cfull = Cfull + Cfull.T
+    wide = -np.diag(np.logspace(-3, 2, n)) + 1e-4 * g.standard_normal((n, n))
+    for A, Cc in ((unstable, Cm), (wide, Cfull)):
         lib.rails_sb03md_set_pause(0)
         s0, b0 = counts()
-        X = solve(A, Cm, b"T")
+        X = solve(A, Cc, b"T")
         s1, b1 = counts()
         assert s1 == s0 and b1 == b0 + 1
-        Xref = sl.solve_continuous_lyapunov(A, Cm)
-        assert np.linalg.norm(X - Xref) <= 1e-9 * np.linalg.norm(Xref)  # conditioning of these problems, same algorithm on both sides
+        Xref = sl.solve_continuous_lyapunov(A, Cc)
+        assert np.linalg.norm(X - Xref) <= 1e-8 * np.linalg.norm(Xref)  # conditioning of these problems, same algorithm on both sides
 
 
 @pytest.mark.parametrize("loops", [0, 1])
