@@ -241,13 +241,13 @@ def main():
     stamps = []  # host time at the end of every trip (diagnostics: one slow trip shows up here)
 
     def on_trip(trip):
-        stamps.append(time.perf_counter())
         if trip == W or trip == W + K:
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             marks[trip] = time.perf_counter()
+        stamps.append(time.perf_counter())
 
     solver.set_trip_callback(on_trip)
     cpu_at_start = os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1
