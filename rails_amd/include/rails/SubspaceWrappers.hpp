@@ -361,6 +361,22 @@ public:
                 ++c0;
             }
         ncols = c0;
+        if (trace) {
+            std::cerr << "compress: dim " << dim << ", " << stores.size() << " live stores, columns in use:";
+            for (auto &st : stores) {
+                int used = 0;
+                for (int j = 0; j < st->ncap; ++j) {
+                    const double *cj = st->col(j);
+                    for (int i = 0; i < dim; ++i)
+                        if (cj[i] != 0.0) {
+                            ++used;
+                            break;
+                        }
+                }
+                std::cerr << " " << used << "/" << st->ncap;
+            }
+            std::cerr << " -> " << ncols << " columns" << std::endl;
+        }
         if (ncols == 0) return;
         std::vector<double> Q((size_t)dim * std::min(dim, ncols));
         int rank = 0, info = 0;

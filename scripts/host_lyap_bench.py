@@ -65,8 +65,8 @@ for n in (128, 200, 256):
     t_evr = best(lambda: lapack.dsyevr(T))
     t_evd = best(lambda: lapack.dsyevd(T))
     print("n=%3d  rails_dsyev %5.2f ms | scipy dsyevd %5.2f | dsyevr %5.2f" % (n, t_ev, t_evd, t_evr), flush=True)
-for dim, ncols in ((354, 300), (450, 330)):
-    Cc = np.asfortranarray(rng.standard_normal((dim, 160)) @ rng.standard_normal((160, ncols)))  # rank 160 of ncols columns
+for dim, ncols, rk in ((354, 300, 160), (347, 308, 292), (450, 330, 300)):
+    Cc = np.asfortranarray(rng.standard_normal((dim, rk)) @ rng.standard_normal((rk, ncols)))  # rank rk of ncols columns
     Q = np.zeros((dim, min(dim, ncols)), order="F")
 
     def rb():
