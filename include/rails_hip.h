@@ -164,6 +164,10 @@ int rails_gram(rails_ctx *ctx, const rails_panel *X, int xc0, int a, const rails
  * column windows coincide exactly (in-place, row-local) or are disjoint. */
 int rails_panel_gemm(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int k, const double *C_host,
                      int ldc, int r, double beta, rails_panel *Y, int yc0);
+/* The same product for any number r of output columns: one upload of C, launches in slices of 128 columns with no host wait in
+ * between (the basis rotation of the coordinate-space back end).  X and Y: different panels or disjoint windows. */
+int rails_panel_gemm_wide(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc, int r,
+                          double beta, rails_panel *Y, int yc0);
 
 /* Orthonormalise columns [k_old, k_old+w) of V against columns [0, k_old) and among themselves,
  * equivalent to the reference's column-wise CGS2 with pre/post normalisation

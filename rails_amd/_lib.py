@@ -58,6 +58,7 @@ SIGNATURES = {
     "rails_panel_random": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rails_gram": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _dp, C.c_int]),
     "rails_panel_gemm": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_double, _vp, C.c_int]),
+    "rails_panel_gemm_wide": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_double, _vp, C.c_int]),
     "rails_orthogonalize": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _ip]),
     "rails_resid_lanczos": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                       _dp, C.c_int, _ip]),

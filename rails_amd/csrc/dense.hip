@@ -413,6 +413,38 @@ int rails_panel_gemm_dev(rails_ctx *c, double alpha, const double *X, int ldx, i
     return RAILS_OK;
 }
 
+// Y[:, yc0:yc0+r] = beta * Y + alpha * X[:, xc0:xc0+k] * C for any r: C goes to the device in ONE upload and the product is launched in
+// slices of 128 output columns (the faster tile shape) without the host waiting in between -- rails_panel_gemm re-uses one staging
+// buffer per call, so a loop over it makes the host wait for every slice's kernel but the last (the basis rotation P <- P Q of the
+// coordinate-space back end: 2.6 ms of host time per restart).  X and Y must be different panels or disjoint windows.
+extern "C" int rails_panel_gemm_wide(rails_ctx *c, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc, int r,
+                                     double beta, rails_panel *Y, int yc0)
+{
+    RAILS_REQUIRE(c && X && Y, "rails_panel_gemm_wide: null argument");
+    RAILS_REQUIRE(k >= 0 && r >= 0 && xc0 >= 0 && yc0 >= 0 && xc0 + k <= X->cap && yc0 + r <= Y->cap,
+                  "rails_panel_gemm_wide: windows [%d,%d) / [%d,%d) outside capacities %d / %d", xc0, xc0 + k, yc0, yc0 + r, X->cap, Y->cap);
+    RAILS_REQUIRE(X->m == Y->m, "rails_panel_gemm_wide: row mismatch %lld vs %lld", (long long)X->m, (long long)Y->m);
+    RAILS_REQUIRE(k == 0 || r == 0 || (C_host && ldc >= k), "rails_panel_gemm_wide: bad coefficient matrix (ldc %d < %d)", ldc, k);
+    if (X->d == Y->d) RAILS_REQUIRE((xc0 + k <= yc0) || (yc0 + r <= xc0), "rails_panel_gemm_wide: overlapping windows of one panel");
+    if (r == 0 || X->m == 0) return RAILS_OK;
+    if (k == 0) {
+        if (beta == 0.0) return rails_panel_fill(c, Y, yc0, r, 0.0);
+        if (beta == 1.0) return RAILS_OK;
+        return rails_panel_scale(c, Y, yc0, r, beta);
+    }
+    size_t n = (size_t)k * r;
+    RAILS_TRY(rails_small_reserve(c, n * sizeof(double)));
+    RAILS_TRY(rails_pinned_begin_write(c, n * sizeof(double)));
+    for (int j = 0; j < r; ++j) memcpy(c->pinned + (size_t)j * k, C_host + (size_t)j * ldc, sizeof(double) * k);
+    RAILS_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RAILS_TRY(rails_pinned_end_write(c));
+    for (int j0 = 0; j0 < r; j0 += 128) {
+        const int nc = std::min(128, r - j0);
+        RAILS_TRY(rails_panel_gemm_dev(c, alpha, X->d + xc0, X->ld, k, c->small + (size_t)j0 * k, nc, beta, Y->d + yc0 + j0, Y->ld, X->m));
+    }
+    return RAILS_OK;
+}
+
 extern "C" int rails_panel_gemm(rails_ctx *c, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc,
                                 int r, double beta, rails_panel *Y, int yc0)
 {

@@ -393,12 +393,9 @@ public:
         P2.resize(rank);
         {
             Tick rot(this, &t_rotate);
-            for (int j0 = 0; j0 < rank; j0 += 128) { // 128 output columns per launch: the faster tile shape of k_panel_gemm
-                int nc = std::min(128, rank - j0);
-                if (!hip_ok(rails_panel_gemm(ctx, 1.0, P.panel(), 0, dim, Q.data() + (size_t)j0 * dim, dim, nc, 0.0, P2.panel(), j0), "rails_panel_gemm")) {
-                    failed = true;
-                    return;
-                }
+            if (!hip_ok(rails_panel_gemm_wide(ctx, 1.0, P.panel(), 0, dim, Q.data(), dim, rank, 0.0, P2.panel(), 0), "rails_panel_gemm_wide")) {
+                failed = true;
+                return;
             }
         }
         Tick tick(this, &t_recoef);

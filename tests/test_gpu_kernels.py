@@ -401,3 +401,27 @@ def test_resid_lanczos_breakdown(ctx, oracle):
     assert abs(np.abs(out["eigenvalues"]).max() - float(Bh.T @ Bh)) < 1e-9 * float(Bh.T @ Bh)
     assert abs(np.abs(ref["eigenvalues"]).max() - float(Bh.T @ Bh)) < 1e-9 * float(Bh.T @ Bh)
     assert out["steps"] <= 8
+
+
+def test_panel_gemm_wide_matches_numpy(ctx):
+    """rails_panel_gemm_wide: any number of output columns from one upload of C (the basis rotation P <- P Q)"""
+    import ctypes as C
+
+    from rails_amd.wrappers import _p
+
+    g = np.random.default_rng(8)
+    m, k, r = 3001, 75, 300
+    Xh = g.uniform(-1, 1, (m, k))
+    Cm = np.asfortranarray(np.pad(g.uniform(-1, 1, (k, r)), ((0, 5), (0, 0))))  # ldc = k + 5
+    Yh0 = g.uniform(-1, 1, (m, r))
+    X = MV(ctx, data=Xh)
+    Y = MV(ctx, m=m, n=r + 3, capacity=r + 3)
+    for alpha, beta in ((1.0, 0.0), (-0.5, 1.0)):
+        Yv = Y.view(2, r + 1)
+        Yv.from_host(Yh0)
+        rc = ctx.lib.rails_panel_gemm_wide(ctx.h, alpha, X.panel.h, 0, k, _p(Cm), k + 5, r, beta, Y.panel.h, 2)
+        assert rc == 0
+        want = beta * Yh0 + alpha * (Xh @ Cm[:k])
+        np.testing.assert_allclose(Yv.to_host(), want, rtol=0, atol=1e-13 * k)
+    # overlapping windows of one panel are refused
+    assert ctx.lib.rails_panel_gemm_wide(ctx.h, 1.0, Y.panel.h, 0, 10, _p(Cm), k + 5, 20, 0.0, Y.panel.h, 5) != 0
