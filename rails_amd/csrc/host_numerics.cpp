@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <utility>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -534,9 +535,37 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
     double a = 0.8 / amin, b = 1.2 * bmax;
     if (!(a < b)) a = 0.5 * b;
     if (b / a > 1e5) return false;
-    const int L = std::min(8, std::max(2, (int)std::ceil(0.5 * std::log2(b / a)) + 1));
-    std::vector<double> shift(L);
-    for (int i = 0; i < L; ++i) shift[i] = a * std::pow(b / a, (2.0 * i + 1.0) / (2.0 * L));
+    // Wachspress' optimal real ADI parameters for [a, b]: with L = 2^s of them one sweep damps every mode by
+    // rho_L ~ 4 exp(-pi^2 L / ln(4 b/a)); the 2L parameters of [a, b] follow from the L parameters x of [sqrt(ab), (a+b)/2] as
+    // x +- sqrt(x^2 - ab).  A factorisation costs about four 16-column solves, so L is the power of two with the smallest
+    // 4 L + (terms needed for 1e-8.5 in Z, i.e. 1e-17 in X).
+    const double kappa = b / a, pi = 3.14159265358979323846;
+    int L = 1;
+    double best_cost = 1e300;
+    for (int cand = 1; cand <= 8; cand *= 2) {
+        double rho = cand == 1 ? (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0) : std::min(0.999, 4.0 * std::exp(-pi * pi * cand / std::log(4.0 * kappa)));
+        double sweeps = std::ceil(std::log(3e-9) / std::log(std::max(rho, 1e-300)));
+        double cost = 4.0 * cand + cand * std::max(1.0, sweeps);
+        if (cost < best_cost) best_cost = cost, L = cand;
+    }
+    std::vector<double> shift(1, std::sqrt(a * b));
+    {
+        // intervals down the recursion, then the parameters back up
+        std::vector<std::pair<double, double>> iv(1, std::make_pair(a, b));
+        for (int l = L; l > 1; l /= 2) iv.push_back(std::make_pair(std::sqrt(iv.back().first * iv.back().second), 0.5 * (iv.back().first + iv.back().second)));
+        shift.assign(1, std::sqrt(iv.back().first * iv.back().second));
+        for (int lev = (int)iv.size() - 2; lev >= 0; --lev) {
+            const double ab = iv[lev].first * iv[lev].second;
+            std::vector<double> up;
+            for (double x : shift) {
+                const double d = std::sqrt(std::max(0.0, x * x - ab));
+                up.push_back(x + d);
+                up.push_back(x - d);
+            }
+            shift.swap(up);
+        }
+        std::sort(shift.begin(), shift.end());
+    }
     std::vector<std::vector<double>> LUs(L);
     std::vector<std::vector<int>> ips(L, std::vector<int>(n));
     for (int i = 0; i < L; ++i) {
@@ -546,7 +575,7 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
         if (info != 0) return false;
     }
     const size_t blk = (size_t)n * rank;
-    const int max_terms = 12 * L, max_cols = 6 * n;
+    const int max_terms = std::max(64, 16 * L), max_cols = 8 * n;
     std::vector<double> Z, T(blk);
     Z.reserve(blk * 24);
     auto norm2 = [&](const double *z) {
@@ -582,8 +611,11 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
             converged = true;
             break;
         }
-        if (cur == L - 1) { // end of a cycle: the terms must have shrunk by a clear factor, or this is not the right tool
-            if (n2 > 0.2 * cycle_start) return false;
+        if (cur == L - 1) { // end of a cycle: against the same term of the cycle before it must have shrunk by a clear factor
+            if (j >= 2 * L - 1 && n2 > 0.2 * cycle_start) {
+                if (trace_lr) fprintf(stderr, "sb03md ADI: n %d, spectrum ~[%.3g, %.3g], %d shifts: term %d is %.2e of the same term one cycle earlier -- giving up\n", n, a, b, L, j, n2 / cycle_start);
+                return false;
+            }
             cycle_start = n2;
         }
     }
