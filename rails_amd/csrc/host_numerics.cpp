@@ -43,6 +43,8 @@ typedef void (*lp_dgemm)(const char *, const char *, const int *, const int *, c
                          const int *, const double *, const int *, const double *, double *, const int *);
 typedef void (*lp_dtrsm)(const char *, const char *, const char *, const char *, const int *, const int *, const double *, const double *,
                          const int *, double *, const int *);
+typedef void (*lp_dsyrk)(const char *, const char *, const int *, const int *, const double *, const double *, const int *, const double *,
+                         double *, const int *);
 typedef void (*lp_dgetrf)(const int *, const int *, double *, const int *, int *, int *);
 typedef void (*lp_dgetrs)(const char *, const int *, const int *, const double *, const int *, const int *, double *, const int *, int *);
 }
@@ -62,6 +64,7 @@ struct HostLapack {
     lp_dorgqr dorgqr = nullptr;
     lp_dgemm dgemm = nullptr;
     lp_dtrsm dtrsm = nullptr; // optional: the generalized projected solve falls back to loops
+    lp_dsyrk dsyrk = nullptr;   // optional: X = Z Z' of the factored ADI route
     lp_dgetrf dgetrf = nullptr; // optional: the squared-Smith fast path of rails_sb03md
     lp_dgetrs dgetrs = nullptr;
 } g_lp;
@@ -94,6 +97,7 @@ bool try_open(const std::string &path)
     L.dpotrf = (lp_dpotrf)lookup(h, "dpotrf_");
     L.dgemm = (lp_dgemm)lookup(h, "dgemm_");
     L.dtrsm = (lp_dtrsm)lookup(h, "dtrsm_");
+    L.dsyrk = (lp_dsyrk)lookup(h, "dsyrk_");
     L.dgetrf = (lp_dgetrf)lookup(h, "dgetrf_");
     L.dgetrs = (lp_dgetrs)lookup(h, "dgetrs_");
     L.dpstrf = (lp_dpstrf)lookup(h, "dpstrf_");
@@ -623,13 +627,20 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
     if (!converged) return false;
     const int cols = (int)(Z.size() / n);
     std::vector<double> Y(nn);
-    gemm('N', 'T', n, n, cols, Z.data(), n, Z.data(), n, Y.data(), n);
-    for (int j = 0; j < n; ++j)
-        for (int i = 0; i < j; ++i) {
-            const double vv = 0.5 * (Y[i + (size_t)j * n] + Y[j + (size_t)i * n]);
-            Y[i + (size_t)j * n] = vv;
-            Y[j + (size_t)i * n] = vv;
-        }
+    if (g_lp.dsyrk) { // the upper triangle at half the flops, mirrored
+        const double one_d = 1.0, zero_d = 0.0;
+        g_lp.dsyrk("U", "N", &n, &cols, &one_d, Z.data(), &n, &zero_d, Y.data(), &n);
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < j; ++i) Y[j + (size_t)i * n] = Y[i + (size_t)j * n];
+    } else {
+        gemm('N', 'T', n, n, cols, Z.data(), n, Z.data(), n, Y.data(), n);
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < j; ++i) {
+                const double vv = 0.5 * (Y[i + (size_t)j * n] + Y[j + (size_t)i * n]);
+                Y[i + (size_t)j * n] = vv;
+                Y[j + (size_t)i * n] = vv;
+            }
+    }
     for (size_t q = 0; q < nn; ++q) Y[q] *= -sign; // M Y + Y M' = C
     // verification with the ORIGINAL right-hand side (also covers the truncation of the pivoted Cholesky factor)
     gemm('N', 'N', n, n, n, M.data(), n, Y.data(), n, W.data(), n);
