@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <utility>
 #include <cmath>
 #include <cstdio>
@@ -484,6 +485,14 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
 {
     if (!g_lp.dgetrf || !g_lp.dgetrs) return false;
     static const bool trace_lr = getenv("RAILS_SB03MD_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_mark = t_begin, t_factor = 0, t_bounds = 0, t_lu = 0, t_terms = 0, t_form = 0;
+    auto lap = [&](double &acc) {
+        const double t = now();
+        acc += t - t_mark;
+        t_mark = t;
+    };
     const size_t nn = (size_t)n * n;
     std::vector<double> C(nn), W(nn);
     double trc = 0.0, dmax = 0.0;
@@ -505,6 +514,7 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
     std::vector<double> M(nn);
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < n; ++i) M[i + (size_t)j * n] = tr ? A[i + (size_t)j * lda] : A[j + (size_t)i * lda];
+    lap(t_factor);
     // extent of the spectrum: b ~ largest, a ~ smallest modulus (power / inverse iteration from a fixed start vector)
     const char N = 'N';
     const int one = 1;
@@ -538,6 +548,7 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
     if (!(amin > 0.0) || !(bmax > 0.0) || !std::isfinite(amin) || !std::isfinite(bmax)) return false;
     double a = 0.8 / amin, b = 1.2 * bmax;
     if (!(a < b)) a = 0.5 * b;
+    lap(t_bounds);
     if (b / a > 1e5) return false;
     // Wachspress' optimal real ADI parameters for [a, b]: with L = 2^s of them one sweep damps every mode by
     // rho_L ~ 4 exp(-pi^2 L / ln(4 b/a)); the 2L parameters of [a, b] follow from the L parameters x of [sqrt(ab), (a+b)/2] as
@@ -578,6 +589,7 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
         g_lp.dgetrf(&n, &n, LUs[i].data(), &n, ips[i].data(), &info);
         if (info != 0) return false;
     }
+    lap(t_lu);
     const size_t blk = (size_t)n * rank;
     const int max_terms = std::max(64, 16 * L), max_cols = 8 * n;
     std::vector<double> Z, T(blk);
@@ -623,6 +635,7 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
             cycle_start = n2;
         }
     }
+    lap(t_terms);
     if (trace_lr) fprintf(stderr, "sb03md ADI: n %d rank %d, spectrum ~[%.3g, %.3g], %d shifts, %d terms, converged %d\n", n, rank, a, b, L, (int)(Z.size() / blk), (int)converged);
     if (!converged) return false;
     const int cols = (int)(Z.size() / n);
@@ -653,7 +666,10 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
             y2 += Y[i + (size_t)j * n] * Y[i + (size_t)j * n];
             c2 += C[i + (size_t)j * n] * C[i + (size_t)j * n];
         }
-    if (trace_lr) fprintf(stderr, "sb03md ADI: residual %.2e of %.2e allowed\n", std::sqrt(r2), 2e-15 * (2.0 * std::sqrt(m2 * y2) + std::sqrt(c2)));
+    lap(t_form);
+    if (trace_lr)
+        fprintf(stderr, "sb03md ADI: residual %.2e of %.2e allowed; ms: factor C %.2f, bounds %.2f, %d LU %.2f, terms %.2f, X = ZZ' + check %.2f, total %.2f\n", std::sqrt(r2),
+                2e-15 * (2.0 * std::sqrt(m2 * y2) + std::sqrt(c2)), t_factor, t_bounds, L, t_lu, t_terms, t_form, now() - t_begin);
     if (!(std::sqrt(r2) <= 2e-15 * (2.0 * std::sqrt(m2 * y2) + std::sqrt(c2)))) return false;
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < n; ++i) X[i + (size_t)j * ldx] = Y[i + (size_t)j * n];
