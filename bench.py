@@ -238,6 +238,7 @@ def main():
     solver.set_option("subspace", args.subspace)
     marks = {}
 
+    allocs = []  # device / pinned allocations made by the library so far, per trip
     stamps = []  # host time at the end of every trip (diagnostics: one slow trip shows up here)
 
     def on_trip(trip):
@@ -248,9 +249,9 @@ def main():
             torch.cuda.synchronize()
             marks[trip] = time.perf_counter()
         stamps.append(time.perf_counter())
+        allocs.append(ctx.stats().get("device_allocations", 0))
 
     solver.set_trip_callback(on_trip)
-    cpu_at_start = os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1
     import gc
 
     gc.collect()
@@ -270,8 +271,9 @@ def main():
     log("[rank %d] host sections (s, whole solve incl. warm-up): %s" % (rank, json.dumps(solver.profile())))
     if len(stamps) > W + 2:
         dts = np.diff(np.array(stamps))[W:]
-        log("[rank %d] timed trips: median %.2f ms, slowest %.2f ms (trip %d); host thread on cpu %d -> %d" % (
-            rank, 1e3 * float(np.median(dts)), 1e3 * float(dts.max()), W + 1 + int(dts.argmax()), cpu_at_start, os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1))
+        log("[rank %d] timed trips: median %.2f ms, slowest %.2f ms (trip %d); library allocations inside the timed region: %d (at trips %s)" % (
+            rank, 1e3 * float(np.median(dts)), 1e3 * float(dts.max()), W + 1 + int(dts.argmax()), allocs[-1] - allocs[W - 1],
+            [i + 1 for i in range(W, len(allocs)) if allocs[i] != allocs[i - 1]]))
     log("[rank %d] counters: %s %s" % (rank, json.dumps(ctx.stats()), json.dumps(solver.backend_stats())))
     log("[rank %d] %d trips in %.3fs -> %.2f it/s; Lanczos estimates %.3e -> %.3e; V.N()=%d" % (rank, K, elapsed, its, hist[0], hist[-1], solver.k))
 

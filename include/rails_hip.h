@@ -205,6 +205,9 @@ int rails_lanczos_release(rails_ctx *ctx); /* frees the Lanczos vectors kept by 
 
 /* ---------------------------------------------------------- timing helpers --- */
 /* HIP-event timing on the context's stream (bench.py's roofline leg). */
+/* Make room for `bytes` of coefficient uploads / small results now (pinned staging buffer and its device counterpart) instead
+ * of at the call that first needs it. */
+int rails_ctx_reserve_staging(rails_ctx *ctx, size_t bytes);
 int rails_timer_start(rails_ctx *ctx);
 int rails_timer_stop(rails_ctx *ctx, double *ms);
 

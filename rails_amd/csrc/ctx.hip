@@ -81,9 +81,9 @@ extern "C" int rails_ctx_stats(rails_ctx *c, char *buf, int cap)
 {
     RAILS_REQUIRE(c && buf && cap > 0, "rails_ctx_stats: bad argument");
     int n = snprintf(buf, (size_t)cap,
-                     "{\"orth_block\": %ld, \"orth_columnwise\": %ld, \"spmm_tiled\": %ld, \"spmm_rowgather\": %ld, \"spmm_callback\": %ld, \"allreduce\": %ld, "
+                     "{\"orth_block\": %ld, \"orth_columnwise\": %ld, \"spmm_tiled\": %ld, \"spmm_rowgather\": %ld, \"spmm_callback\": %ld, \"device_allocations\": %ld, \"allreduce\": %ld, "
                      "\"lanczos\": %ld, \"lanczos_start\": %ld, \"orth_repair\": %ld}",
-                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_rowgather, c->n_spmm_callback, c->n_allreduce, c->n_lanczos, c->n_lanczos_start, c->n_orth_repair);
+                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_rowgather, c->n_spmm_callback, c->n_dev_alloc, c->n_allreduce, c->n_lanczos, c->n_lanczos_start, c->n_orth_repair);
     RAILS_REQUIRE(n > 0 && n < cap, "rails_ctx_stats: buffer too small");
     return RAILS_OK;
 }
@@ -155,7 +155,9 @@ static int grow(rails_ctx *c, double **p, size_t *have, size_t need, bool host)
         *p = nullptr;
         *have = 0;
     }
-    size_t sz = need + need / 4 + 4096;
+    size_t sz = 2 * need + 4096; // doubling: these buffers follow the basis dimension, which creeps up restart by restart
+    c->n_dev_alloc++;
+    if (getenv("RAILS_TRACE_ALLOC")) fprintf(stderr, "rails alloc: %s buffer grows to %zu bytes\n", host ? "pinned" : "device", sz);
     hipError_t e = host ? hipHostMalloc((void **)p, sz, hipHostMallocDefault) : hipMalloc((void **)p, sz);
     if (e != hipSuccess) {
         rails_set_error("allocation of %zu bytes failed: %s", sz, hipGetErrorString(e));
@@ -168,6 +170,15 @@ static int grow(rails_ctx *c, double **p, size_t *have, size_t need, bool host)
 int rails_ws_reserve(rails_ctx *c, size_t bytes) { return grow(c, &c->ws, &c->ws_bytes, bytes, false); }
 int rails_small_reserve(rails_ctx *c, size_t bytes) { return grow(c, &c->small, &c->small_bytes, bytes, false); }
 int rails_pinned_reserve(rails_ctx *c, size_t bytes) { return grow(c, &c->pinned, &c->pinned_bytes, bytes, true); }
+
+// room for coefficient uploads / small results of `bytes` in both the pinned staging buffer and its device counterpart, made now
+// rather than in the middle of a solve (every growth synchronises the stream and calls the allocator)
+extern "C" int rails_ctx_reserve_staging(rails_ctx *c, size_t bytes)
+{
+    RAILS_REQUIRE(c, "null context");
+    RAILS_TRY(rails_small_reserve(c, bytes));
+    return rails_pinned_reserve(c, bytes);
+}
 
 int rails_pinned_begin_write(rails_ctx *c, size_t bytes)
 {
@@ -215,6 +226,8 @@ extern "C" int rails_panel_create(rails_ctx *c, int64_t m_local, int capacity, r
     P->cap = capacity;
     P->ld = rails_pad_ld(capacity);
     size_t bytes = (size_t)(m_local > 0 ? m_local : 1) * P->ld * sizeof(double);
+    c->n_dev_alloc++;
+    if (getenv("RAILS_TRACE_ALLOC")) fprintf(stderr, "rails alloc: panel %lld x %d (%zu bytes)\n", (long long)m_local, capacity, bytes);
     hipError_t e = hipMalloc((void **)&P->d, bytes);
     if (e != hipSuccess) {
         rails_set_error("rails_panel_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -273,6 +286,8 @@ extern "C" int rails_panel_reserve(rails_ctx *c, rails_panel *P, int capacity)
     }
     double *nd = nullptr;
     size_t bytes = (size_t)(P->m > 0 ? P->m : 1) * nld * sizeof(double);
+    c->n_dev_alloc++;
+    if (getenv("RAILS_TRACE_ALLOC")) fprintf(stderr, "rails alloc: panel reserve %lld x %d -> %d (%zu bytes)\n", (long long)P->m, P->cap, capacity, bytes);
     hipError_t e = hipMalloc((void **)&nd, bytes);
     if (e != hipSuccess) {
         rails_set_error("rails_panel_reserve: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));

@@ -69,7 +69,7 @@ struct rails_ctx {
     bool h2d_pending = false;
     // counters (rails_ctx_stats)
     void *lz = nullptr; // rails_lanczos_state (lanczos.hip), released by rails_lanczos_release
-    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0;
+    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_dev_alloc = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0;
 };
 
 struct rails_panel {

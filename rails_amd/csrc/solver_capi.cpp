@@ -176,6 +176,7 @@ static int solve_in_coordinates(rails_solver *s)
     const int expand = s->params.get("Expand size", 3);
     const int kmax = std::max(restart > 0 ? restart : 100, 1) + expand + 100;
     auto basis = std::make_shared<rails::SubspaceBasis>(s->ctx, s->m_local, s->m_global, 2 * kmax + p + 128);
+    if (restart > 0 || s->params.get("Restart iterations", 20) > 0) basis->preallocate_compress_panel(); // restarts will re-base the basis
     rails::SubspaceMultiVector Bc = rails::SubspaceMultiVector::Absorb(basis, s->B);
     rails::SubspaceOperator Ac(s->A, basis);
     rails::SubspaceOperator Mc(s->mass ? s->M : s->A, basis);

@@ -91,6 +91,18 @@ public:
         P.resize(0);
     }
 
+    // the ping-pong panel of compress(), allocated up front (same capacity as P) where a multi-gigabyte device allocation in the
+    // middle of a solve would hurt: hipMalloc of 3 GB takes 1-70 ms on the shared boxes
+    void preallocate_compress_panel()
+    {
+        const size_t cap = (size_t)P.capacity();
+        hip_ok(rails_ctx_reserve_staging(ctx, cap * cap / 2 * sizeof(double)), "rails_ctx_reserve_staging"); // the rotation's Q, Gram results
+        if (P2.N() >= 0 && P2.capacity() >= P.capacity()) return;
+        P2 = HipMultiVectorWrapper(m_local, P.capacity(), ctx);
+        P2.set_global_rows(m_global);
+        P2.resize(0);
+    }
+
     std::shared_ptr<CoefStore> new_store(int ncap, bool in_basis, int rows = 0)
     {
         auto s = std::make_shared<CoefStore>(in_basis ? row_cap : rows, ncap, in_basis);
