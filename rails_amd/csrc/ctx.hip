@@ -59,6 +59,8 @@ extern "C" int rails_ctx_destroy(rails_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     rails_lanczos_release(c);
+    for (auto &fp : c->free_panels) hipFree(fp.second);
+    c->free_panels.clear();
     if (c->ws) hipFree(c->ws);
     if (c->small) hipFree(c->small);
     if (c->pinned) hipHostFree(c->pinned);
@@ -226,13 +228,28 @@ extern "C" int rails_panel_create(rails_ctx *c, int64_t m_local, int capacity, r
     P->cap = capacity;
     P->ld = rails_pad_ld(capacity);
     size_t bytes = (size_t)(m_local > 0 ? m_local : 1) * P->ld * sizeof(double);
-    c->n_dev_alloc++;
-    if (getenv("RAILS_TRACE_ALLOC")) fprintf(stderr, "rails alloc: panel %lld x %d (%zu bytes)\n", (long long)m_local, capacity, bytes);
-    hipError_t e = hipMalloc((void **)&P->d, bytes);
-    if (e != hipSuccess) {
-        rails_set_error("rails_panel_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        delete P;
-        return RAILS_ENOMEM;
+    for (size_t q = 0; q < c->free_panels.size() && !P->d; ++q)
+        if (c->free_panels[q].first == bytes) {
+            P->d = c->free_panels[q].second;
+            c->free_panel_bytes -= bytes;
+            c->free_panels.erase(c->free_panels.begin() + (long)q);
+        }
+    if (!P->d) {
+        c->n_dev_alloc++;
+        if (getenv("RAILS_TRACE_ALLOC")) fprintf(stderr, "rails alloc: panel %lld x %d (%zu bytes)\n", (long long)m_local, capacity, bytes);
+        hipError_t e = hipMalloc((void **)&P->d, bytes);
+        if (e != hipSuccess && !c->free_panels.empty()) { // give the cached buffers back and try again
+            hipStreamSynchronize(c->stream);
+            for (auto &fp : c->free_panels) hipFree(fp.second);
+            c->free_panels.clear();
+            c->free_panel_bytes = 0;
+            e = hipMalloc((void **)&P->d, bytes);
+        }
+        if (e != hipSuccess) {
+            rails_set_error("rails_panel_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            delete P;
+            return RAILS_ENOMEM;
+        }
     }
     // padding columns are read by vectorised kernels: keep them finite
     RAILS_HIP_CHECK(hipMemsetAsync(P->d, 0, bytes, c->stream));
@@ -244,8 +261,16 @@ extern "C" int rails_panel_destroy(rails_panel *P)
 {
     if (!P) return RAILS_OK;
     if (P->d) {
-        hipStreamSynchronize(P->ctx->stream);
-        hipFree(P->d);
+        rails_ctx *c = P->ctx;
+        const size_t bytes = (size_t)(P->m > 0 ? P->m : 1) * P->ld * sizeof(double);
+        // keep up to 8 GiB of buffers for re-use (work queued on the stream may still read this one: the next user is on the same stream)
+        if (bytes <= ((size_t)2 << 30) && c->free_panel_bytes + bytes <= ((size_t)8 << 30) && c->free_panels.size() < 64) {
+            c->free_panels.push_back(std::make_pair(bytes, P->d));
+            c->free_panel_bytes += bytes;
+        } else {
+            hipStreamSynchronize(c->stream);
+            hipFree(P->d);
+        }
     }
     delete P;
     return RAILS_OK;

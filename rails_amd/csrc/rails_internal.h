@@ -57,6 +57,10 @@ struct rails_ctx {
     // device workspace for reduction partials / small matrices
     double *ws = nullptr;
     size_t ws_bytes = 0;
+    // device buffers of destroyed panels, kept for the next panel of the same size (stream-ordered re-use: no synchronisation,
+    // no allocator call inside a solve that creates and drops temporaries of a few recurring sizes)
+    std::vector<std::pair<size_t, double *>> free_panels;
+    size_t free_panel_bytes = 0;
     // second device scratch (small matrices uploaded per call)
     double *small = nullptr;
     size_t small_bytes = 0;
