@@ -179,7 +179,7 @@ def main():
             X = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk + args.spmm_pad)
             Y = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk + args.spmm_pad)
             X.random()
-            for variant in ((1, 2) if args.spmm_variant == 0 else (args.spmm_variant,)):
+            for variant in ((1, 2, 7) if args.spmm_variant == 0 else (args.spmm_variant,)):
                 A.set_variant(variant)
                 try:
                     for _ in range(3):

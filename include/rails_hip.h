@@ -122,10 +122,28 @@ int rails_spmm(rails_ctx *ctx, rails_csr *A, int trans, const rails_panel *X, in
 
 /* Kernel variant control for benchmarking and tests: 0 = auto, 1 = row-gather kernel (column chunking by the window
  * heuristic), 2 = LDS-staged footprint kernel, 3 = row-gather over the whole width, 4 / 5 = row-gather in 32 / 64 column
- * chunks inside one launch, 6 = LDS-staged footprint kernel with 16-column chunks (whole 128-B lines per staged row). */
+ * chunks inside one launch, 6 = LDS-staged footprint kernel with 16-column chunks (whole 128-B lines per staged row),
+ * 7 = sweep kernel (banded patterns: X streamed once per XCD through LDS rings, partial sums in registers; fails when the
+ * pattern or the column count does not fit), 8 = never the sweep kernel (auto otherwise). */
 int rails_csr_set_variant(rails_csr *A, int variant);
+/* Statistics of the sweep kernel's schedule for nc columns, once a product of that width has built it:
+ * out[0] slot efficiency, [1] X rows staged per matrix row and chunk, [2] lock-step trips, [3] 1 if the schedule exists. */
+int rails_csr_sweep_stats(rails_csr *A, int nc, double *out);
 /* name of the kernel the last rails_spmm on A launched */
 const char *rails_csr_last_kernel(const rails_csr *A);
+
+/* Host-side schedule of the sweep kernel (rails_amd/csrc/sweep_plan.h), exposed for tests and diagnostics: no device is
+ * touched.  params = {waves, groups, rows per step, ring segments, parts, phases} or NULL for the kernel's own geometry.
+ * info: iinfo[0..5] = params, [6] bytes per step record, [7] lock-step trips, [8] nnz, [9] batches; dinfo[0] = slot
+ * efficiency nnz / (8 trips), dinfo[1] = X rows staged per matrix row and column chunk.  rails_sweep_plan_array lends the
+ * arrays of the plan (which = 0 part_row0 i64, 1 sweep0 i64, 2 nsteps i32, 3 hdr_off i64, 4 batch_off i64, 5 flush_off i64,
+ * 6 codes u8, 7 vals f64, 8 offs u16, 9 flush_rows i32); they live until rails_sweep_plan_destroy. */
+typedef struct rails_sweep_plan rails_sweep_plan;
+int rails_sweep_plan_create(int64_t m, int64_t ncols, const int64_t *rowptr, const int32_t *col, const double *val,
+                            const int *params, rails_sweep_plan **out);
+int rails_sweep_plan_destroy(rails_sweep_plan *plan);
+int rails_sweep_plan_info(const rails_sweep_plan *plan, int64_t *iinfo, double *dinfo);
+int rails_sweep_plan_array(const rails_sweep_plan *plan, int which, const void **ptr, int64_t *count);
 
 /* ------------------------------------------------------------------ panels --- */
 

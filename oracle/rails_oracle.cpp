@@ -946,4 +946,86 @@ int orc_solve(int m, const double *Adense, int lda, const int64_t *rp, const int
     return ret;
 }
 
+
+// ----------------------------------------------------------------------------
+// Interpreter of the sweep-SpMM schedule (rails_amd/csrc/sweep_plan.h): executes, on the CPU and in the order the HIP
+// kernel does, the program of every (part, phase, chunk, wave) and checks the two things the kernel relies on -- every
+// ring row a trip reads holds the X row the schedule meant (it arrived, and is not the segment being refilled), and every
+// row of Y is written exactly once.  Y = A X then follows from the schedule alone, so comparing it with orc_csr_spmm
+// pins the planner without a GPU.  Replaces nothing in the reference (`A_ * W`, src/LyapunovSolver.hpp:146, is the
+// product being scheduled).  X, Y column-major.  Returns 0, or -1 ring row not readable, -2 row written twice,
+// -3 row never written, -4 trips left in a program's stream.
+// ----------------------------------------------------------------------------
+int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const int64_t *sweep0, const int32_t *nsteps,
+                        const int64_t *hdr_off, const int64_t *batch_off, const int64_t *flush_off, const uint8_t *codes,
+                        const double *vals, const uint16_t *offs, const int32_t *flush_rows, int64_t m, int64_t ncols, int n_chunks,
+                        const double *X, int64_t ldx, double *Y, int64_t ldy)
+{
+    const int W = (int)iinfo[0], G = (int)iinfo[1], SEG = (int)iinfo[2], NSEG = (int)iinfo[3], parts = (int)iinfo[4], P = (int)iinfo[5];
+    const int CPS = (int)iinfo[6]; // bytes per (program, step) record
+    std::vector<int> written((size_t)m * n_chunks, 0);
+    int rc = 0;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+    for (int x = 0; x < parts; ++x)
+        for (int q = 0; q < n_chunks; ++q) {
+            std::vector<double> acc((size_t)G * 8 * 16);
+            for (int ph = 0; ph < P; ++ph)
+                for (int w = 0; w < W; ++w) {
+                    const int64_t prog = ((int64_t)x * P + ph) * W + w;
+                    std::fill(acc.begin(), acc.end(), 0.0);
+                    int64_t trip = 0, fl = 0;
+                    for (int k = 0; k < nsteps[x]; ++k)
+                        for (int g = 0; g < G; ++g) {
+                            const int code = codes[hdr_off[prog] + (int64_t)k * CPS + g];
+                            const int T = 4 * (code & 0x7f);
+                            for (int t = 0; t < T; ++t, ++trip) {
+                                const int64_t b = batch_off[prog] + trip / 16;
+                                for (int s = 0; s < 8; ++s) {
+                                    const size_t at = (size_t)b * 128 + (size_t)s * 16 + (size_t)(trip % 8) * 2 + (size_t)(trip % 16) / 8;
+                                    const double v = vals[at];
+                                    const int o = offs[at];
+                                    const int seg = o / SEG;
+                                    const int back = ((k - seg) % NSEG + NSEG) % NSEG; // steps since that segment was filled
+                                    const int kk = k - back;
+                                    if (seg >= NSEG || kk < 0 || back > NSEG - 2) {
+#pragma omp atomic write
+                                        rc = -1;
+                                        continue;
+                                    }
+                                    int64_t xrow = sweep0[x] + (int64_t)kk * SEG + o % SEG;
+                                    xrow = xrow < 0 ? 0 : (xrow >= ncols ? ncols - 1 : xrow);
+                                    double *a = &acc[((size_t)g * 8 + s) * 16];
+                                    for (int c = 0; c < 16; ++c) a[c] += v * X[xrow + (int64_t)(q * 16 + c) * ldx];
+                                }
+                            }
+                            if (code & 0x80) {
+                                const int64_t row0 = flush_rows[flush_off[prog] + fl++];
+                                for (int s = 0; s < 8; ++s) {
+                                    const int64_t row = row0 + s;
+                                    double *a = &acc[((size_t)g * 8 + s) * 16];
+                                    if (row < part_row0[x + 1]) {
+                                        for (int c = 0; c < 16; ++c) Y[row + (int64_t)(q * 16 + c) * ldy] = a[c];
+#pragma omp atomic
+                                        written[(size_t)row * n_chunks + q]++;
+                                    }
+                                    for (int c = 0; c < 16; ++c) a[c] = 0.0;
+                                }
+                            }
+                        }
+                    // the wave's stream must be used up exactly: the next program starts at the next batch boundary
+                    const int64_t nprog = (int64_t)parts * P * W;
+                    if (prog + 1 < nprog && batch_off[prog + 1] != batch_off[prog] + (trip + 15) / 16) {
+#pragma omp atomic write
+                        rc = -4;
+                    }
+                }
+        }
+    if (rc) return rc;
+    for (size_t i = 0; i < written.size(); ++i) {
+        if (written[i] > 1) return -2;
+        if (written[i] < 1) return -3;
+    }
+    return 0;
+}
+
 } // extern "C"

@@ -41,7 +41,12 @@ SIGNATURES = {
     "rails_csr_set_halo": (C.c_int, [_vp, C.c_int64, _i64p, C.c_int64, HALO_FN, _vp]),
     "rails_spmm": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int]),
     "rails_csr_set_variant": (C.c_int, [_vp, C.c_int]),
+    "rails_csr_sweep_stats": (C.c_int, [_vp, C.c_int, _dp]),
     "rails_csr_last_kernel": (C.c_char_p, [_vp]),
+    "rails_sweep_plan_create": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, _dp, _ip, C.POINTER(_vp)]),
+    "rails_sweep_plan_destroy": (C.c_int, [_vp]),
+    "rails_sweep_plan_info": (C.c_int, [_vp, _i64p, _dp]),
+    "rails_sweep_plan_array": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _i64p]),
     "rails_panel_create": (C.c_int, [_vp, C.c_int64, C.c_int, C.POINTER(_vp)]),
     "rails_panel_destroy": (C.c_int, [_vp]),
     "rails_panel_rows": (C.c_int64, [_vp]),

@@ -73,7 +73,7 @@ struct rails_ctx {
     bool h2d_pending = false;
     // counters (rails_ctx_stats)
     void *lz = nullptr; // rails_lanczos_state (lanczos.hip), released by rails_lanczos_release
-    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_dev_alloc = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0;
+    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_sweep = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_dev_alloc = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0;
 };
 
 struct rails_panel {
@@ -84,8 +84,11 @@ struct rails_panel {
     int ld = 0;
 };
 
+struct rails_sweep_cache; // spmm_sweep.hip: device copies of the sweep kernel's schedules, one per column-chunk count
+
 struct rails_csr {
     rails_ctx *ctx = nullptr;
+    rails_sweep_cache *sweep = nullptr;
     int64_t m = 0, ncols_ext = 0, nnz = 0;
     int64_t *rowptr = nullptr;
     int32_t *col = nullptr;
@@ -141,6 +144,10 @@ int rails_pinned_end_write(rails_ctx *ctx);
 int rails_allreduce_dev(rails_ctx *ctx, double *dev, size_t n);
 
 // ---- kernels / launchers across translation units ----
+// spmm_sweep.hip: the sweep kernel for banded patterns; *done tells whether it computed the product
+int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool aligned,
+                     bool force, bool *done);
+void rails_sweep_release(rails_csr *A);
 // dense.hip: partial Gram into device memory (no host copy / all-reduce): C_dev (a x b col-major, ldc = a)
 int rails_gram_dev(rails_ctx *ctx, const double *X, int ldx, const double *Y, int ldy, int64_t m, int a, int b,
                    double *C_dev);

@@ -373,6 +373,7 @@ extern "C" int rails_csr_destroy(rails_csr *A)
     if (!A) return RAILS_OK;
     hipStreamSynchronize(A->ctx->stream);
     if (A->AT) rails_csr_destroy(A->AT);
+    rails_sweep_release(A);
     if (A->rowptr) hipFree(A->rowptr);
     if (A->col) hipFree(A->col);
     if (A->val) hipFree(A->val);
@@ -398,7 +399,7 @@ extern "C" const char *rails_csr_last_kernel(const rails_csr *A) { return A ? A-
 
 extern "C" int rails_csr_set_variant(rails_csr *A, int variant)
 {
-    RAILS_REQUIRE(A && variant >= 0 && variant <= 6, "rails_csr_set_variant: bad argument");
+    RAILS_REQUIRE(A && variant >= 0 && variant <= 8, "rails_csr_set_variant: bad argument");
     A->variant = variant;
     return RAILS_OK;
 }
@@ -495,6 +496,14 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     }
     bool done = false;
     const bool vec2 = ((xc0 | yc0) & 1) == 0 && (ldg % 2 == 0);
+    // banded patterns at panel width: the sweep kernel (spmm_sweep.hip).  Auto: the window of a row block (window_rows + block) has
+    // to fit (phases - 1) blocks of 2816 rows, and every XCD's part should hold a few blocks per phase.
+    if (A->variant == 7 || (A->variant == 0 && (nc == 128 || nc == 64) && A->n_ghost == 0 && A->window_rows > 0 &&
+                            A->window_rows + 2816 <= (int64_t)(32 / (nc / 16) - 1) * 2816 && A->m >= (int64_t)8 * 4 * (32 / (nc / 16)) * 2816 / 4)) {
+        const bool al = ((xc0 | yc0) & 1) == 0 && X->ld % 2 == 0 && Y->ld % 2 == 0 && ldg % 2 == 0;
+        RAILS_TRY(rails_spmm_sweep(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, al, A->variant == 7, &done));
+        if (done) return RAILS_OK;
+    }
     if (A->variant == 0 || A->variant == 2 || A->variant == 6) RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, vec2, X->ld - xc0, &done));
     if (done) c->n_spmm_tiled++;
     if (!done) {

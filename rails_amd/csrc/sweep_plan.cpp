@@ -1,0 +1,345 @@
+// sweep_plan.cpp -- builds the schedule the sweep SpMM kernel interprets (see sweep_plan.h).  Host code only.
+#include "sweep_plan.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+constexpr int SLOTS = 8;
+
+struct GroupSchedule {
+    std::vector<uint8_t> count;   // [nsteps] units of 4 trips | flush << 7
+    std::vector<double> val;      // [trips][8]
+    std::vector<uint16_t> off;    // [trips][8]
+    std::vector<int32_t> flush;   // first row of the wave's slot octet, per flush, in step order
+};
+
+struct Ctx {
+    const rails_sweep_params *prm;
+    const int64_t *rowptr;
+    const int32_t *col;
+    const double *val;
+    int64_t r0, r1;     // rows of the part
+    int64_t sweep0;
+    int nsteps;
+    int64_t R;          // rows per block
+    int64_t nblocks;
+};
+
+// schedule of one (phase, wave, group) of a part; false = not feasible
+bool schedule_group(const Ctx &c, int phase, int wave, int g, GroupSchedule &out, std::string &why)
+{
+    const rails_sweep_params &P = *c.prm;
+    const int SEG = P.seg_rows, NSEG = P.nseg;
+    const int ring = SEG * NSEG;
+    out.count.assign(c.nsteps, 0);
+    out.val.clear();
+    out.off.clear();
+    out.flush.clear();
+    int64_t bj = phase; // current block of this workgroup
+    // state of the current block
+    int64_t p[SLOTS], pe[SLOTS]; // next / end nonzero of each slot's row
+    int64_t last_pos[SLOTS];
+    bool loaded = false, any_valid = false;
+    int64_t cur_row0 = 0;
+    auto load_block = [&](int64_t j) {
+        cur_row0 = c.r0 + j * c.R + (int64_t)g * P.waves * SLOTS + (int64_t)wave * SLOTS;
+        any_valid = false;
+        for (int s = 0; s < SLOTS; ++s) {
+            const int64_t row = cur_row0 + s;
+            last_pos[s] = -1;
+            if (row < c.r1 && row < c.r0 + (j + 1) * c.R) {
+                p[s] = c.rowptr[row];
+                pe[s] = c.rowptr[row + 1];
+                any_valid = true;
+            } else
+                p[s] = pe[s] = 0;
+        }
+        loaded = true;
+    };
+    // first sweep segment of the first nonzero of block j for this group (INT64_MAX: none)
+    auto first_seg = [&](int64_t j) -> int64_t {
+        if (j >= c.nblocks) return INT64_MAX;
+        const int64_t row0 = c.r0 + j * c.R + (int64_t)g * P.waves * SLOTS + (int64_t)wave * SLOTS;
+        int64_t best = INT64_MAX;
+        for (int s = 0; s < SLOTS; ++s) {
+            const int64_t row = row0 + s;
+            if (row < c.r1 && row < c.r0 + (j + 1) * c.R && c.rowptr[row + 1] > c.rowptr[row])
+                best = std::min<int64_t>(best, ((int64_t)c.col[c.rowptr[row]] - c.sweep0) / SEG);
+        }
+        return best;
+    };
+    int64_t next_first = INT64_MAX;
+    for (int k = 0; k < c.nsteps; ++k) {
+        if (!loaded) {
+            if (bj >= c.nblocks) break;
+            load_block(bj);
+            // the next block WITH nonzeros bounds how long this one may take
+            next_first = INT64_MAX;
+            for (int64_t j = bj + P.phases; j < c.nblocks && next_first == INT64_MAX; j += P.phases) next_first = first_seg(j);
+        }
+        const int64_t hi = (int64_t)(k + 1) * SEG;
+        const int64_t lo = (int64_t)(k - NSEG + 2) * SEG;                            // readable: [lo, hi)
+        const int64_t lo_next = (k == c.nsteps - 1) ? INT64_MAX : lo + SEG;          // gone after this step
+        int forced = 0, remaining = 0;
+        bool all_available = true;
+        for (int s = 0; s < SLOTS; ++s) {
+            int f = 0;
+            for (int64_t q = p[s]; q < pe[s]; ++q) {
+                const int64_t pos = (int64_t)c.col[q] - c.sweep0;
+                if (pos < lo) {
+                    why = "a nonzero lost its X row before it was consumed (columns of a row not sorted?)";
+                    return false;
+                }
+                if (pos < lo_next)
+                    ++f;
+                else
+                    break;
+            }
+            forced = std::max(forced, f);
+            remaining = std::max<int>(remaining, (int)(pe[s] - p[s]));
+            if (pe[s] > p[s] && (int64_t)c.col[pe[s] - 1] - c.sweep0 >= hi) all_available = false;
+        }
+        // the block has to be done before the first X row of the workgroup's next block leaves the ring
+        const bool must_finish = next_first != INT64_MAX && (int64_t)k >= next_first + NSEG - 3;
+        int T = forced;
+        if (must_finish || remaining == 0) {
+            if (!all_available) {
+                why = "the column window of a row block is wider than (phases - 1) blocks";
+                return false;
+            }
+            T = remaining;
+        }
+        // trips come in units of four (the kernel's unit: four ring rows in flight, then four multiply-adds per lane)
+        const int units = (T + 3) / 4;
+        T = units * 4;
+        if (units > 127) {
+            why = "more than 508 nonzeros of one row inside one ring of X rows";
+            return false;
+        }
+        for (int t = 0; t < T; ++t) {
+            double v[SLOTS];
+            int64_t o[SLOTS];
+            int first_real = -1;
+            for (int s = 0; s < SLOTS; ++s) {
+                v[s] = 0.0;
+                o[s] = -1;
+                if (p[s] < pe[s]) {
+                    const int64_t pos = (int64_t)c.col[p[s]] - c.sweep0;
+                    if (pos < hi) {
+                        v[s] = c.val[p[s]];
+                        o[s] = pos;
+                        last_pos[s] = pos;
+                        ++p[s];
+                        if (first_real < 0) first_real = s;
+                    }
+                }
+            }
+            for (int s = 0; s < SLOTS; ++s) {
+                // an idle slot multiplies an X row by zero: its own last one while that is still in the ring, else a neighbour's
+                // (a trip that only rounds a unit up to four has no neighbour: the newest row of the ring)
+                if (o[s] < 0) o[s] = (last_pos[s] >= 0 && last_pos[s] >= lo) ? last_pos[s] : (first_real >= 0 ? o[first_real] : hi - 1);
+                out.val.push_back(v[s]);
+                out.off.push_back((uint16_t)(o[s] % ring));
+            }
+        }
+        bool done = true;
+        for (int s = 0; s < SLOTS; ++s) done = done && p[s] == pe[s];
+        uint8_t code = (uint8_t)units;
+        if (done) {
+            if (any_valid) {
+                code |= 0x80;
+                out.flush.push_back((int32_t)cur_row0);
+            }
+            loaded = false;
+            bj += P.phases;
+        }
+        out.count[k] = code;
+    }
+    if (loaded || bj < c.nblocks) {
+        // blocks left over after the last step: only possible for rows without nonzeros beyond the swept range
+        why = "row blocks left after the last sweep step";
+        return false;
+    }
+    return true;
+}
+
+} // namespace
+
+bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t ncols, const int64_t *rowptr, const int32_t *col,
+                            const double *val, rails_sweep_plan &plan)
+{
+    plan = rails_sweep_plan();
+    plan.p = prm;
+    plan.m = m;
+    plan.ncols = ncols;
+    plan.nnz = rowptr[m];
+    const int W = prm.waves, G = prm.groups, P = prm.phases, SEG = prm.seg_rows;
+    if (W < 1 || G < 1 || G > RAILS_SWEEP_CODES || P < 1 || prm.parts < 1 || prm.nseg < 3 || SEG < 8 || SEG % 8 || (int64_t)SEG * prm.nseg > 65536) {
+        plan.why = "bad parameters";
+        return false;
+    }
+    const int64_t R = (int64_t)G * W * SLOTS;
+    plan.part_row0.resize(prm.parts + 1);
+    for (int x = 0; x <= prm.parts; ++x) plan.part_row0[x] = m * x / prm.parts;
+    plan.sweep0.assign(prm.parts, 0);
+    plan.nsteps.assign(prm.parts, 1);
+    const int64_t nprog = (int64_t)prm.parts * P * W;
+    plan.hdr_off.assign(nprog, 0);
+    plan.batch_off.assign(nprog, 0);
+    plan.flush_off.assign(nprog, 0);
+    // rows must list their columns in ascending order (the sweep consumes them in that order)
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t q = rowptr[i] + 1; q < rowptr[i + 1]; ++q)
+            if (col[q] < col[q - 1]) {
+                plan.why = "columns of a row are not sorted";
+                return false;
+            }
+    int64_t staged = 0;
+    std::vector<GroupSchedule> gs(G);
+    for (int x = 0; x < prm.parts; ++x) {
+        Ctx c;
+        c.prm = &prm;
+        c.rowptr = rowptr;
+        c.col = col;
+        c.val = val;
+        c.r0 = plan.part_row0[x];
+        c.r1 = plan.part_row0[x + 1];
+        c.R = R;
+        c.nblocks = (c.r1 - c.r0 + R - 1) / R;
+        int64_t cmin = INT64_MAX, cmax = -1;
+        for (int64_t i = c.r0; i < c.r1; ++i)
+            if (rowptr[i + 1] > rowptr[i]) {
+                cmin = std::min<int64_t>(cmin, col[rowptr[i]]);
+                cmax = std::max<int64_t>(cmax, col[rowptr[i + 1] - 1]);
+            }
+        if (cmax < 0) cmin = cmax = 0;
+        c.sweep0 = cmin;
+        // at least one step per block of a workgroup, so that blocks of rows without nonzeros still get their zeros written
+        const int64_t by_blocks = (c.nblocks + P - 1) / P;
+        c.nsteps = (int)std::max<int64_t>((cmax - cmin) / SEG + 1, by_blocks);
+        plan.sweep0[x] = c.sweep0;
+        plan.nsteps[x] = c.nsteps;
+        staged += (int64_t)c.nsteps * SEG * P;
+        for (int ph = 0; ph < P; ++ph)
+            for (int w = 0; w < W; ++w) {
+                const int64_t prog = ((int64_t)x * P + ph) * W + w;
+                for (int g = 0; g < G; ++g)
+                    if (!schedule_group(c, ph, w, g, gs[g], plan.why)) return false;
+                // serialise: per step a fixed-size record of RAILS_SWEEP_CODES bytes, byte g = units of four trips | flush << 7;
+                // the trips in (step, group) order, 16 trips per batch: lane q of a slot holds trips q and q + 8 of the batch
+                plan.hdr_off[prog] = (int64_t)plan.codes.size();
+                plan.codes.resize(plan.codes.size() + (size_t)c.nsteps * RAILS_SWEEP_CODES, (uint8_t)0);
+                uint8_t *h = plan.codes.data() + plan.hdr_off[prog];
+                plan.batch_off[prog] = (int64_t)(plan.vals.size() / 128);
+                plan.flush_off[prog] = (int64_t)plan.flush_rows.size();
+                std::vector<size_t> tp(G, 0), fp(G, 0); // per group: next trip / next flush
+                int64_t trip = 0;                       // trips of this wave so far
+                for (int k = 0; k < c.nsteps; ++k)
+                    for (int g = 0; g < G; ++g) {
+                        const uint8_t code = gs[g].count[k];
+                        h[(size_t)k * RAILS_SWEEP_CODES + g] = code;
+                        const int T = 4 * (code & 0x7f);
+                        for (int t = 0; t < T; ++t, ++trip) {
+                            const int64_t b = plan.batch_off[prog] + trip / 16;
+                            if ((size_t)(b + 1) * 128 > plan.vals.size()) {
+                                plan.vals.resize((size_t)(b + 1) * 128, 0.0);
+                                plan.offs.resize((size_t)(b + 1) * 128, 0);
+                            }
+                            for (int s = 0; s < SLOTS; ++s) {
+                                const size_t at = (size_t)b * 128 + (size_t)s * 16 + (size_t)(trip % 8) * 2 + (size_t)(trip % 16) / 8;
+                                plan.vals[at] = gs[g].val[tp[g] * 8 + s];
+                                plan.offs[at] = gs[g].off[tp[g] * 8 + s];
+                            }
+                            ++tp[g];
+                        }
+                        if (code & 0x80) plan.flush_rows.push_back(gs[g].flush[fp[g]++]);
+                    }
+                plan.trips += trip;
+            }
+    }
+    // spare batches at the very end: the kernel prefetches ahead of the trips it runs
+    plan.vals.resize(plan.vals.size() + 4 * 128, 0.0);
+    plan.offs.resize(plan.offs.size() + 4 * 128, 0);
+    plan.entries = plan.nnz;
+    plan.efficiency = plan.trips ? (double)plan.nnz / (8.0 * (double)plan.trips) : 1.0;
+    plan.staged_rows_per_row = m ? (double)staged / (double)m : 0.0;
+    return true;
+}
+
+// ---- C ABI (include/rails_hip.h): host-side access to the schedule for tests and diagnostics ----
+#include "rails_hip.h"
+
+void rails_set_error(const char *fmt, ...);
+
+extern "C" int rails_sweep_plan_create(int64_t m, int64_t ncols, const int64_t *rowptr, const int32_t *col, const double *val,
+                                       const int *params, rails_sweep_plan **out)
+{
+    if (!rowptr || !out || m < 0 || (rowptr[m] > 0 && (!col || !val))) {
+        rails_set_error("rails_sweep_plan_create: bad argument");
+        return RAILS_EINVAL;
+    }
+    rails_sweep_params prm;
+    if (params) {
+        prm.waves = params[0];
+        prm.groups = params[1];
+        prm.seg_rows = params[2];
+        prm.nseg = params[3];
+        prm.parts = params[4];
+        prm.phases = params[5];
+    }
+    rails_sweep_plan *pl = new rails_sweep_plan();
+    if (!rails_sweep_plan_build(prm, m, ncols, rowptr, col, val, *pl)) {
+        rails_set_error("rails_sweep_plan_create: pattern does not fit the sweep scheme: %s", pl->why.c_str());
+        delete pl;
+        return RAILS_EINVAL;
+    }
+    *out = pl;
+    return RAILS_OK;
+}
+
+extern "C" int rails_sweep_plan_destroy(rails_sweep_plan *pl)
+{
+    delete pl;
+    return RAILS_OK;
+}
+
+extern "C" int rails_sweep_plan_info(const rails_sweep_plan *pl, int64_t *iinfo, double *dinfo)
+{
+    if (!pl || !iinfo || !dinfo) return RAILS_EINVAL;
+    iinfo[0] = pl->p.waves;
+    iinfo[1] = pl->p.groups;
+    iinfo[2] = pl->p.seg_rows;
+    iinfo[3] = pl->p.nseg;
+    iinfo[4] = pl->p.parts;
+    iinfo[5] = pl->p.phases;
+    iinfo[6] = RAILS_SWEEP_CODES;
+    iinfo[7] = pl->trips;
+    iinfo[8] = pl->nnz;
+    iinfo[9] = (int64_t)(pl->vals.size() / 128);
+    dinfo[0] = pl->efficiency;
+    dinfo[1] = pl->staged_rows_per_row;
+    return RAILS_OK;
+}
+
+extern "C" int rails_sweep_plan_array(const rails_sweep_plan *pl, int which, const void **ptr, int64_t *count)
+{
+    if (!pl || !ptr || !count) return RAILS_EINVAL;
+    switch (which) {
+    case 0: *ptr = pl->part_row0.data(); *count = (int64_t)pl->part_row0.size(); break;
+    case 1: *ptr = pl->sweep0.data(); *count = (int64_t)pl->sweep0.size(); break;
+    case 2: *ptr = pl->nsteps.data(); *count = (int64_t)pl->nsteps.size(); break;
+    case 3: *ptr = pl->hdr_off.data(); *count = (int64_t)pl->hdr_off.size(); break;
+    case 4: *ptr = pl->batch_off.data(); *count = (int64_t)pl->batch_off.size(); break;
+    case 5: *ptr = pl->flush_off.data(); *count = (int64_t)pl->flush_off.size(); break;
+    case 6: *ptr = pl->codes.data(); *count = (int64_t)pl->codes.size(); break;
+    case 7: *ptr = pl->vals.data(); *count = (int64_t)pl->vals.size(); break;
+    case 8: *ptr = pl->offs.data(); *count = (int64_t)pl->offs.size(); break;
+    case 9: *ptr = pl->flush_rows.data(); *count = (int64_t)pl->flush_rows.size(); break;
+    default: return RAILS_EINVAL;
+    }
+    return RAILS_OK;
+}

@@ -1,0 +1,67 @@
+// sweep_plan.h -- host-side plan of the LDS-window ("sweep") SpMM, spmm_sweep.hip.
+//
+// The kernel computes Y = A X (replaces `A_ * W`, src/LyapunovSolver.hpp:146) for matrices whose rows reference a
+// bounded window of columns (banded patterns).  Every workgroup streams a contiguous range of X rows ONCE through a
+// ring of LDS segments, 16 columns wide, while the partial sums of the rows it owns live in registers; the order in
+// which the nonzeros are consumed is fixed per matrix on the host (this file), so that the device code has no
+// searching, no comparisons and no divergence: it interprets a schedule.
+//
+// Geometry (all sizes are parameters of the plan; the kernel instantiates W, G and fixes the rest):
+//   parts    the rows are cut into `parts` contiguous ranges, one per XCD (8): the workgroups of a part sweep the
+//            same X rows at the same time, so each X row is fetched from HBM once per part and served to the others
+//            by that XCD's L2
+//   chunks   column chunks of 16 (a 128-B line per X row); `phases` = workgroups per (part, chunk)
+//   blocks   a part's rows are cut into blocks of R = G * W * 8 rows; block j belongs to phase j % phases; a
+//            workgroup owns one block at a time: G groups x W waves x 8 slots, one row per slot, 16 partial sums
+//            per row spread over the slot's 8 lanes
+//   steps    sweep position s = column - sweep0(part); step k brings positions [k*SEG, (k+1)*SEG) into ring
+//            segment k % NSEG while the lanes may read positions [(k-NSEG+2)*SEG, (k+1)*SEG)
+//   trips    one trip = every slot of a wave consumes at most one nonzero of its row (lock step); trips come in units
+//            of four; per step and group the schedule gives the number of units; a group's partial sums are written
+//            to Y when its block is done
+#ifndef RAILS_SWEEP_PLAN_H
+#define RAILS_SWEEP_PLAN_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+constexpr int RAILS_SWEEP_CODES = 64; // bytes per (program, step) record: one byte per lane of a wave; groups <= 64
+
+struct rails_sweep_params {
+    int waves = 8;      // W: waves per workgroup
+    int groups = 44;    // G: row groups per wave (each: 8 slots = 8 rows)
+    int seg_rows = 256; // SEG: X rows per step
+    int nseg = 5;       // ring segments (NSEG - 1 are readable while one is being filled)
+    int parts = 8;      // row ranges (XCDs)
+    int phases = 4;     // workgroups per (part, column chunk)
+};
+
+struct rails_sweep_plan {
+    rails_sweep_params p;
+    int64_t m = 0, ncols = 0, nnz = 0;
+    std::vector<int64_t> part_row0;          // [parts + 1]
+    std::vector<int64_t> sweep0;             // [parts] column of sweep position 0
+    std::vector<int32_t> nsteps;             // [parts]
+    // one program per (part, phase, wave): index (part * phases + phase) * W + wave
+    std::vector<int64_t> hdr_off;            // [programs] offset into codes
+    std::vector<int64_t> batch_off;          // [programs] first batch (16 trips) in vals / offs
+    std::vector<int64_t> flush_off;          // [programs] offset into flush_rows
+    std::vector<uint8_t> codes;              // per (program, step) RAILS_SWEEP_CODES bytes: byte g = units of 4 trips | flush << 7
+    std::vector<double> vals;                // per batch of 16 trips: [slot 8][trip % 8][trip / 8]
+    std::vector<uint16_t> offs;              // same indexing: ring row of the X row to read
+    std::vector<int32_t> flush_rows;         // first row (of the wave's 8 x G rows: + g * 64 * ... see kernel) per flush
+    // statistics
+    int64_t trips = 0;                       // lock-step trips over all programs
+    int64_t entries = 0;                     // = nnz when feasible
+    double efficiency = 0.0;                 // nnz / (8 * trips)
+    double staged_rows_per_row = 0.0;        // X rows staged per matrix row and chunk (1 + window / R for a band)
+    std::string why;                         // reason when not feasible
+};
+
+// Builds the plan; returns false (plan.why says why) when the pattern does not fit the scheme with these parameters:
+// a block's rows still need X rows that have not arrived when the rows of the next block of the same workgroup lose theirs.
+bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t ncols, const int64_t *rowptr, const int32_t *col,
+                            const double *val, rails_sweep_plan &plan);
+
+#endif

@@ -349,6 +349,12 @@ class HipOperatorWrapper:
     def last_kernel(self):
         return self.ctx.lib.rails_csr_last_kernel(self.h.h).decode()
 
+    def sweep_stats(self, nc):
+        """Schedule statistics of the sweep kernel for nc columns (zeros until a product of that width has built the schedule)."""
+        out = (C.c_double * 4)()
+        check(self.ctx.lib.rails_csr_sweep_stats(self.h.h, nc, out), "rails_csr_sweep_stats")
+        return {"efficiency": out[0], "staged_rows_per_row": out[1], "trips": int(out[2]), "built": bool(out[3])}
+
     def set_halo(self, plan, pyfunc):
         """Install the ghost-row plan (rails_amd.partition.HaloPlan) and hook pyfunc(send_ptr, recv_ptr, ncols, stream)."""
         def tramp(user, send, recv, nc, stream):

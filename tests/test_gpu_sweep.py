@@ -1,0 +1,143 @@
+"""The sweep SpMM kernel (rails_amd/csrc/spmm_sweep.hip; `A_ * W`, src/LyapunovSolver.hpp:146, on banded patterns) through the C ABI.
+
+Every row's nonzeros are consumed in ascending column order with one fused multiply-add each, from zero: the same chain as
+the row-gather kernel, so the two HIP kernels must agree BIT FOR BIT; against the CPU oracle (separate multiply and add)
+the bound is the SpMM tolerance of tests/test_gpu_kernels.py, 1e-14 * sqrt(nnz/row) relative.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import rails_amd
+
+    c = rails_amd.Context(device=0, seed=77)
+    yield c
+    c.close()
+
+
+def _panels(ctx, m, nc, xoff=0, yoff=0, seed=0):
+    import rails_amd
+
+    Xh = np.random.default_rng(seed).uniform(-1, 1, (m, nc))
+    big = rails_amd.HipMultiVectorWrapper(ctx, m=m, n=nc + xoff, capacity=nc + xoff)
+    X = big.view(xoff, xoff + nc - 1)
+    X.from_host(Xh)
+    outp = rails_amd.HipMultiVectorWrapper(ctx, m=m, n=nc + yoff, capacity=nc + yoff + 2)
+    Y = outp.view(yoff, yoff + nc - 1)
+    return Xh, X, Y, outp
+
+
+@pytest.mark.parametrize("m,nc,xoff,yoff", [(131072, 128, 0, 0), (150001, 128, 2, 4), (131072, 64, 0, 0), (100000, 32, 0, 2), (70000, 16, 6, 0)])
+def test_sweep_is_bitwise_the_rowgather_result_and_matches_the_oracle(ctx, oracle, m, nc, xoff, yoff):
+    import rails_amd
+    from rails_amd import problems as P
+
+    A = P.banded_random(m, 27, 4096 if nc >= 64 else 1500, seed=m % 7)
+    op = rails_amd.HipOperatorWrapper(ctx, *A)
+    Xh, X, Y, outp = _panels(ctx, m, nc, xoff, yoff, seed=nc)
+    outp.assign(0.0)
+    op.set_variant(7)
+    op.apply(X, Y)
+    assert op.last_kernel() == "k_spmm_sweep"
+    st = op.sweep_stats(nc)
+    assert st["built"] and st["efficiency"] > 0.5
+    Ys = Y.to_host()
+    op.set_variant(3)
+    op.apply(X, Y)
+    assert op.last_kernel() == "k_spmm_rowgather"
+    Yr = Y.to_host()
+    assert np.array_equal(Ys, Yr), np.abs(Ys - Yr).max()
+    rows = np.random.default_rng(1).choice(m, 4000, replace=False)
+    rows = np.concatenate([rows, np.arange(64), np.arange(m - 64, m)])
+    rp, col, val = A
+    ref = np.zeros((rows.size, nc))
+    for k, i in enumerate(rows):
+        ref[k] = val[rp[i]:rp[i + 1]] @ Xh[col[rp[i]:rp[i + 1]]]
+    assert np.abs(Ys[rows] - ref).max() <= 4e-14 * np.sqrt(27) * np.abs(ref).max()
+    if yoff:
+        assert np.array_equal(outp.to_host()[:, :yoff], np.zeros((m, yoff)))  # columns outside the window untouched
+
+
+def test_sweep_handles_ragged_rows_and_rows_without_entries(ctx, oracle):
+    import rails_amd
+
+    g = np.random.default_rng(9)
+    m = 120000
+    cnt = g.integers(0, 40, m)
+    cnt[::113] = 0
+    rowptr = np.zeros(m + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(cnt)
+    col = np.empty(rowptr[-1], dtype=np.int32)
+    for i in range(m):
+        col[rowptr[i]:rowptr[i + 1]] = np.sort(np.clip(i + g.integers(-3000, 3000, cnt[i]), 0, m - 1))
+    val = g.uniform(-1, 1, col.size)
+    op = rails_amd.HipOperatorWrapper(ctx, rowptr, col, val)
+    Xh, X, Y, outp = _panels(ctx, m, 128, seed=3)
+    Y.assign(7.0)
+    op.set_variant(7)
+    op.apply(X, Y)
+    Ys = Y.to_host()
+    ref = oracle.csr_spmm(rowptr, col, val, Xh)
+    assert np.abs(Ys - ref).max() <= 4e-14 * np.sqrt(40) * np.abs(ref).max()
+    assert np.array_equal(Ys[::113], np.zeros_like(Ys[::113]))
+    op.set_variant(3)
+    op.apply(X, Y)
+    assert np.array_equal(Ys, Y.to_host())
+
+
+def test_sweep_declines_what_it_cannot_do(ctx):
+    import rails_amd
+    from rails_amd import problems as P
+
+    U = P.uniform_random(200000, 9, seed=4)
+    op = rails_amd.HipOperatorWrapper(ctx, *U)
+    Xh, X, Y, _ = _panels(ctx, 200000, 128)
+    op.set_variant(7)
+    with pytest.raises(rails_amd.RailsError, match="does not fit"):
+        op.apply(X, Y)
+    op.set_variant(0)  # auto falls back to the row-gather kernel
+    op.apply(X, Y)
+    assert op.last_kernel().startswith("k_spmm_rowgather")
+    A = P.banded_random(140000, 27, 4096, seed=1)
+    op2 = rails_amd.HipOperatorWrapper(ctx, *A)
+    Xh, X, Y, _ = _panels(ctx, 140000, 24)
+    op2.set_variant(7)
+    with pytest.raises(rails_amd.RailsError, match="multiple of 16"):
+        op2.apply(X, Y)
+
+
+def test_auto_choice_on_the_bench_matrix_and_its_transpose(ctx):
+    """BASELINE configs[2] at full size: auto picks the sweep kernel at 128 columns; linearity and the adjoint identity hold."""
+    import rails_amd
+    from rails_amd import problems as P
+
+    m = 1000000
+    A = P.banded_random(m, 27, 4096, seed=1)
+    op = rails_amd.HipOperatorWrapper(ctx, *A)
+    X = rails_amd.HipMultiVectorWrapper(ctx, m=m, n=128, capacity=128)
+    Z = rails_amd.HipMultiVectorWrapper(ctx, m=m, n=128, capacity=128)
+    X.random()
+    Z.random()
+    Y = op.apply(X)
+    assert op.last_kernel() == "k_spmm_sweep"
+    op.set_variant(3)
+    Yr = op.apply(X)
+    d = Y.copy()
+    d -= Yr
+    assert d.norm() == 0.0  # bitwise equal to the row-gather kernel on all 128M entries
+    op.set_variant(0)
+    # A * ones = row sums (the generator makes them -1 exactly up to rounding of the sum)
+    ones = rails_amd.HipMultiVectorWrapper(ctx, m=m, n=128, capacity=128)
+    ones.assign(1.0)
+    rs = op.apply(ones).to_host()[:, [0, 127]]
+    rp, col, val = A
+    assert np.abs(rs - np.add.reduceat(val, rp[:-1])[:, None]).max() < 1e-12
+    # adjoint identity <Z, A X> = <A^T Z, X> through the transposed operator (its own schedule)
+    lhs = Z.dot(Y)
+    AtZ = op.transpose().apply(Z)
+    rhs = AtZ.dot(X)
+    assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(lhs).max()
