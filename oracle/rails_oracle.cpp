@@ -957,12 +957,12 @@ int orc_solve(int m, const double *Adense, int lda, const int64_t *rp, const int
 // -3 row never written, -4 trips left in a program's stream.
 // ----------------------------------------------------------------------------
 int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const int64_t *sweep0, const int32_t *nsteps,
-                        const int64_t *hdr_off, const int64_t *batch_off, const int64_t *flush_off, const uint8_t *codes,
+                        const int64_t *hdr_off, const int64_t *batch_off, const int64_t *flush_off, const uint16_t *codes,
                         const double *vals, const uint16_t *offs, const int32_t *flush_rows, int64_t m, int64_t ncols, int n_chunks,
                         const double *X, int64_t ldx, double *Y, int64_t ldy)
 {
     const int W = (int)iinfo[0], G = (int)iinfo[1], SEG = (int)iinfo[2], NSEG = (int)iinfo[3], parts = (int)iinfo[4], P = (int)iinfo[5];
-    const int CPS = (int)iinfo[6]; // bytes per (program, step) record
+    const int CPS = (int)iinfo[6]; // entries per (program, step) record
     std::vector<int> written((size_t)m * n_chunks, 0);
     int rc = 0;
 #pragma omp parallel for collapse(2) schedule(dynamic)
@@ -975,9 +975,15 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
                     std::fill(acc.begin(), acc.end(), 0.0);
                     int64_t trip = 0, fl = 0;
                     for (int k = 0; k < nsteps[x]; ++k)
-                        for (int g = 0; g < G; ++g) {
-                            const int code = codes[hdr_off[prog] + (int64_t)k * CPS + g];
-                            const int T = 4 * (code & 0x7f);
+                        for (int ci = 1; ci <= (int)codes[hdr_off[prog] + (int64_t)k * CPS]; ++ci) {
+                            const int code = codes[hdr_off[prog] + (int64_t)k * CPS + ci];
+                            const int g = code & 63;
+                            const int T = (code & 0x80) ? 0 : 4;
+                            if (g >= G || ci >= CPS) {
+#pragma omp atomic write
+                                rc = -1;
+                                continue;
+                            }
                             for (int t = 0; t < T; ++t, ++trip) {
                                 const int64_t b = batch_off[prog] + trip / 16;
                                 for (int s = 0; s < 8; ++s) {
@@ -998,7 +1004,7 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
                                     for (int c = 0; c < 16; ++c) a[c] += v * X[xrow + (int64_t)(q * 16 + c) * ldx];
                                 }
                             }
-                            if (code & 0x80) {
+                            if (code & 0x40) {
                                 const int64_t row0 = flush_rows[flush_off[prog] + fl++];
                                 for (int s = 0; s < 8; ++s) {
                                     const int64_t row = row0 + s;

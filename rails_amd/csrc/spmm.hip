@@ -496,10 +496,10 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     }
     bool done = false;
     const bool vec2 = ((xc0 | yc0) & 1) == 0 && (ldg % 2 == 0);
-    // banded patterns at panel width: the sweep kernel (spmm_sweep.hip).  Auto: the window of a row block (window_rows + block) has
-    // to fit (phases - 1) blocks of 2816 rows, and every XCD's part should hold a few blocks per phase.
+    // banded patterns at panel width: the sweep kernel (spmm_sweep.hip).  Auto: the window of columns of a row has to fit
+    // (phases - 1) blocks of 2816 rows (the planner decides exactly), and every XCD's part should hold a few blocks per phase.
     if (A->variant == 7 || (A->variant == 0 && (nc == 128 || nc == 64) && A->n_ghost == 0 && A->window_rows > 0 &&
-                            A->window_rows + 2816 <= (int64_t)(32 / (nc / 16) - 1) * 2816 && A->m >= (int64_t)8 * 4 * (32 / (nc / 16)) * 2816 / 4)) {
+                            A->window_rows + 256 <= (int64_t)(32 / (nc / 16) - 1) * 2816 && A->m >= (int64_t)8 * 4 * (32 / (nc / 16)) * 2816 / 4)) {
         const bool al = ((xc0 | yc0) & 1) == 0 && X->ld % 2 == 0 && Y->ld % 2 == 0 && ldg % 2 == 0;
         RAILS_TRY(rails_spmm_sweep(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, al, A->variant == 7, &done));
         if (done) return RAILS_OK;

@@ -39,22 +39,38 @@ struct SweepArgs {
     int ablate; // experiments only (RAILS_SWEEP_ABLATE): 1 = no LDS-DMA after the first step, 2 = no trips (results are wrong either way)
 };
 
-// quad broadcast of quad lane T; shifts by four lanes inside a row of 16 (= two slots) that only write one quad of each slot
-#define RAILS_BCQ(x, T) __builtin_amdgcn_update_dpp(0, (int)(x), (T) * 0x55, 0xf, 0xf, true)
-#define RAILS_LO_TO_HI(x) __builtin_amdgcn_update_dpp((int)(x), (int)(x), 0x114 /* row_shr:4 */, 0xf, 0xa, false)
-#define RAILS_HI_TO_LO(x) __builtin_amdgcn_update_dpp((int)(x), (int)(x), 0x104 /* row_shl:4 */, 0xf, 0x5, false)
+// ---- register plan -------------------------------------------------------------------------------------------------
+// The compiler gets v0-v23 (amdgpu_num_vgpr(24)): per-step work only (LDS-DMA addresses, the step's record, the rare flush).
+// Everything above is addressed by the inline assembly below only:
+//   v[24 .. 24 + 4 G)     the partial sums: group g = v[24 + 4 g .. 24 + 4 g + 3] (two doubles per lane), read and written through
+//                         M0-relative register indexing (s_set_gpr_idx_on), so that ONE copy of the unit's code serves every
+//                         group: with the groups as a register array indexed by constants the loop over groups has to be
+//                         unrolled, and 44 copies of a unit's code (80 KB) thrash the instruction cache (4.0 ms per product)
+//   v[200:215]            the four ring rows of a unit; v[216:219] two broadcast values; v220-v222 the unit's (value lo, value hi,
+//                         ring row << 7) pairs; v223, v254 ring addresses
+//   v[224 + 4 j .. 227 + 4 j], v[248 + j], j = 0..5   six batches of (value, ring row) pairs, used in turn; a batch is requested
+//                         five batches (80 trips) before its first use and waited for with a counted vmcnt.  They land where they
+//                         are read from: a compiler-managed destination gets copied, behind vmcnt(0), right after the load is issued.
+// The unit loop of a step is ONE assembly block: compiled from C++ the same loop took 44 vector + 42 scalar instructions and
+// 10 branches per unit, half of the time waiting (rocprofv3, profiles/): here ~31 + ~25 with the waits counted per ring row.
+constexpr int SWEEP_ACC0 = 24;
+#define RAILS_SWEEP_RESERVED "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+
+// refill buffer (VREGS, OREG) with the next batch: scalar base addresses + per-lane 32-bit offsets
+#define RAILS_RQ(N, VREGS, OREG) "rq" #N "_%=: global_load_dwordx4 " VREGS ", %[voff], %[vb]\n\tglobal_load_dword " OREG ", %[ooff], %[ob]\n\ts_branch rqd_%=\n\t"
 
 // The schedule pointers are separate __restrict__ kernel arguments: what is read through them is never written by the kernel.
 template <int W, int G>
-__global__ __launch_bounds__(W * 64) void k_spmm_sweep(SweepArgs a, const int64_t *__restrict__ part_row0, const int64_t *__restrict__ sweep0_,
-                                                       const int32_t *__restrict__ nsteps_, const int64_t *__restrict__ hdr_off,
-                                                       const int64_t *__restrict__ batch_off, const int64_t *__restrict__ flush_off,
-                                                       const uint8_t *__restrict__ codes, const double *__restrict__ vals,
-                                                       const uint16_t *__restrict__ offs, const int32_t *__restrict__ flush_rows,
-                                                       const double *__restrict__ X, const double *__restrict__ Xg, double *__restrict__ Y)
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_num_vgpr(24))) void k_spmm_sweep(
+    SweepArgs a, const int64_t *__restrict__ part_row0, const int64_t *__restrict__ sweep0_, const int32_t *__restrict__ nsteps_,
+    const int64_t *__restrict__ hdr_off, const int64_t *__restrict__ batch_off, const int64_t *__restrict__ flush_off,
+    const uint16_t *__restrict__ codes, const double *__restrict__ vals, const uint16_t *__restrict__ offs,
+    const int32_t *__restrict__ flush_rows, const double *__restrict__ X, const double *__restrict__ Xg, double *__restrict__ Y)
 {
-    static_assert(G <= RAILS_SWEEP_CODES && RAILS_SWEEP_CODES == 64, "one code byte per lane");
+    static_assert(SWEEP_ACC0 + 4 * G <= 200, "partial sums must end below the unit's registers");
+    static_assert(RAILS_SWEEP_CODES == 128, "two schedule entries per lane");
     static_assert((SEG / 8) % W == 0, "every wave issues the same number of LDS-DMA instructions per step");
+    static_assert(SEG / 8 / W + 1 == 5, "the counted waits are written for 4 LDS-DMA instructions + 1 record load per step");
     __shared__ __attribute__((aligned(128))) unsigned char ring[RING_BYTES];
     const int part = (int)(blockIdx.x % (unsigned)a.parts);
     const int local = (int)(blockIdx.x / (unsigned)a.parts);
@@ -63,14 +79,16 @@ __global__ __launch_bounds__(W * 64) void k_spmm_sweep(SweepArgs a, const int64_
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
     const int slot = lane >> 3, q = lane & 7;
-    const int lane_off = q * 16;
+    // byte offset of this lane's two columns inside a ring row, plus the ring's address in LDS
+    const uint32_t lane_off = (uint32_t)(q * 16) + (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;
     const int64_t prog = ((int64_t)part * a.phases + phase) * W + wave;
-    const uint8_t *cp = codes + hdr_off[prog] + lane; // lane g reads the byte of group g of a step's record
+    const uint32_t *cp = reinterpret_cast<const uint32_t *>(codes + hdr_off[prog]) + lane; // lane i reads entries 2 i and 2 i + 1 of a step's record
     const int32_t *fp = flush_rows + flush_off[prog];
     const int64_t b0 = batch_off[prog];
     // a batch = 16 trips of the wave: lane q of a slot holds the slot's (value, ring row) of trips q and q + 8
-    const double2_t *vp = reinterpret_cast<const double2_t *>(vals) + (b0 * 8 + slot) * 8 + q;
-    const uint32_t *op = reinterpret_cast<const uint32_t *>(offs) + (b0 * 8 + slot) * 8 + q;
+    // the wave's stream: scalar base addresses + per-lane 32-bit byte offsets that advance by one batch per request
+    const uint64_t vb = (uint64_t)(uintptr_t)(vals + b0 * 128), ob = (uint64_t)(uintptr_t)(offs + b0 * 128);
+    uint32_t voff = (uint32_t)(slot * 8 + q) * 16u, ooff = (uint32_t)(slot * 8 + q) * 4u;
     const int64_t row_end = part_row0[part + 1];
     const int64_t sweep0 = sweep0_[part];
     const int nsteps = nsteps_[part];
@@ -87,112 +105,174 @@ __global__ __launch_bounds__(W * 64) void k_spmm_sweep(SweepArgs a, const int64_
         }
     };
 
-    double2_t acc[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = (double2_t){0.0, 0.0};
+    // zero the partial sums (this statement also tells the compiler which registers the assembly owns)
+    asm volatile(".set rails_i, %c0\n\t.rept %c1\n\tv_mov_b32 v[rails_i], 0\n\t.set rails_i, rails_i + 1\n\t.endr" : : "n"(SWEEP_ACC0), "n"(4 * G)
+                 : RAILS_SWEEP_RESERVED);
 
     stage(0, 0);
-    // Two batches, A and B, used in turn (four units each) and each requested while the other is in use, sixteen trips ahead;
-    // they are never copied, so no wait sits right behind a load.
-    double2_t Av = vp[0], Bv = (double2_t){0.0, 0.0};
-    uint32_t Ao = op[0], Bo = 0;
-    int64_t bnext = 1;
-    int ub = 0, fl = 0, seg = 0;
-    uint32_t code_v = cp[0];
+    // batches 0..4 into buffers 0..4; buffer 5 gets batch 5 when buffer 0 comes into use
+    asm volatile("global_load_dwordx4 v[224:227], %0, %2\n\tglobal_load_dword v248, %1, %3\n\t"
+                 "global_load_dwordx4 v[228:231], %0, %2 offset:1024\n\tglobal_load_dword v249, %1, %3 offset:256\n\t"
+                 "global_load_dwordx4 v[232:235], %0, %2 offset:2048\n\tglobal_load_dword v250, %1, %3 offset:512\n\t"
+                 "global_load_dwordx4 v[236:239], %0, %2 offset:3072\n\tglobal_load_dword v251, %1, %3 offset:768\n\t"
+                 "v_add_u32 %0, 0x1000, %0\n\tv_add_u32 %1, 0x400, %1\n\t"
+                 "global_load_dwordx4 v[240:243], %0, %2\n\tglobal_load_dword v252, %1, %3\n\t"
+                 "v_add_u32 %0, 0x400, %0\n\tv_add_u32 %1, 0x100, %1"
+                 : "+v"(voff), "+v"(ooff) : "s"(vb), "s"(ob) : "memory");
+    int ub = 0;   // unit of the six batches in use next (0..23)
+    int tss = 8;  // batch turns since the last step start (the step's 5 vector-memory instructions are younger than requests older than that)
+    int fl = 0, seg = 0;
+    uint32_t rec_next = cp[0];
     for (int k = 0; k < nsteps; ++k) {
         // step k's rows have landed for every wave, and every wave is done reading the segment refilled next
         __syncthreads();
-        const uint32_t codes_k = code_v;
+        const uint32_t rec = rec_next;
         const int seg_next = seg + 1 == NSEG ? 0 : seg + 1;
         if (k + 1 < nsteps) {
-            code_v = cp[(int64_t)(k + 1) * RAILS_SWEEP_CODES];
-            if (!(a.ablate & 1)) stage(k + 1, seg_next);
+            rec_next = cp[(int64_t)(k + 1) * (RAILS_SWEEP_CODES / 2)];
+            if (!(a.ablate & 1)) {
+                stage(k + 1, seg_next);
+                tss = 0;
+            }
         }
         seg = seg_next;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const uint32_t code = (uint32_t)__builtin_amdgcn_readlane((int)codes_k, g);
-            for (int u = (a.ablate & 2) ? 0 : (int)(code & 0x7fu); u > 0; --u) {
-                // the unit's four trips sit in one quad of every slot: hand them to the other quad
-                int lo, hi, ro;
-                switch (ub) {
-                case 0:
-                    lo = RAILS_LO_TO_HI(__double2loint(Av.x));
-                    hi = RAILS_LO_TO_HI(__double2hiint(Av.x));
-                    ro = RAILS_LO_TO_HI((Ao & 0xffffu) << 7);
-                    break;
-                case 1:
-                    lo = RAILS_HI_TO_LO(__double2loint(Av.x));
-                    hi = RAILS_HI_TO_LO(__double2hiint(Av.x));
-                    ro = RAILS_HI_TO_LO((Ao & 0xffffu) << 7);
-                    break;
-                case 2:
-                    lo = RAILS_LO_TO_HI(__double2loint(Av.y));
-                    hi = RAILS_LO_TO_HI(__double2hiint(Av.y));
-                    ro = RAILS_LO_TO_HI((Ao >> 16) << 7);
-                    break;
-                case 3:
-                    lo = RAILS_HI_TO_LO(__double2loint(Av.y));
-                    hi = RAILS_HI_TO_LO(__double2hiint(Av.y));
-                    ro = RAILS_HI_TO_LO((Ao >> 16) << 7);
-                    break;
-                case 4:
-                    lo = RAILS_LO_TO_HI(__double2loint(Bv.x));
-                    hi = RAILS_LO_TO_HI(__double2hiint(Bv.x));
-                    ro = RAILS_LO_TO_HI((Bo & 0xffffu) << 7);
-                    break;
-                case 5:
-                    lo = RAILS_HI_TO_LO(__double2loint(Bv.x));
-                    hi = RAILS_HI_TO_LO(__double2hiint(Bv.x));
-                    ro = RAILS_HI_TO_LO((Bo & 0xffffu) << 7);
-                    break;
-                case 6:
-                    lo = RAILS_LO_TO_HI(__double2loint(Bv.y));
-                    hi = RAILS_LO_TO_HI(__double2hiint(Bv.y));
-                    ro = RAILS_LO_TO_HI((Bo >> 16) << 7);
-                    break;
-                default:
-                    lo = RAILS_HI_TO_LO(__double2loint(Bv.y));
-                    hi = RAILS_HI_TO_LO(__double2hiint(Bv.y));
-                    ro = RAILS_HI_TO_LO((Bo >> 16) << 7);
-                    break;
-                }
-                // request the batch after next once the one in use has been touched (its wait then covers nothing younger)
-                if (ub == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    Bv = vp[bnext * 64];
-                    Bo = op[bnext * 64];
-                    ++bnext;
-                } else if (ub == 4) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    Av = vp[bnext * 64];
-                    Ao = op[bnext * 64];
-                    ++bnext;
-                }
-                ub = (ub + 1) & 7;
-                // four ring rows in flight per lane, then four multiply-adds per partial sum in trip (= column) order: the same
-                // chain of fused multiply-adds as the row-gather kernel
-                const double2_t x0 = *reinterpret_cast<const double2_t *>(ring + (RAILS_BCQ(ro, 0) + lane_off));
-                const double2_t x1 = *reinterpret_cast<const double2_t *>(ring + (RAILS_BCQ(ro, 1) + lane_off));
-                const double2_t x2 = *reinterpret_cast<const double2_t *>(ring + (RAILS_BCQ(ro, 2) + lane_off));
-                const double2_t x3 = *reinterpret_cast<const double2_t *>(ring + (RAILS_BCQ(ro, 3) + lane_off));
-                const double v0 = __hiloint2double(RAILS_BCQ(hi, 0), RAILS_BCQ(lo, 0));
-                const double v1 = __hiloint2double(RAILS_BCQ(hi, 1), RAILS_BCQ(lo, 1));
-                const double v2 = __hiloint2double(RAILS_BCQ(hi, 2), RAILS_BCQ(lo, 2));
-                const double v3 = __hiloint2double(RAILS_BCQ(hi, 3), RAILS_BCQ(lo, 3));
-                acc[g].x = __builtin_fma(v0, x0.x, acc[g].x);
-                acc[g].y = __builtin_fma(v0, x0.y, acc[g].y);
-                acc[g].x = __builtin_fma(v1, x1.x, acc[g].x);
-                acc[g].y = __builtin_fma(v1, x1.y, acc[g].y);
-                acc[g].x = __builtin_fma(v2, x2.x, acc[g].x);
-                acc[g].y = __builtin_fma(v2, x2.y, acc[g].y);
-                acc[g].x = __builtin_fma(v3, x3.x, acc[g].x);
-                acc[g].y = __builtin_fma(v3, x3.y, acc[g].y);
-            }
-            if (code & 0x80u) {
+        const int n = (a.ablate & 2) ? 0 : (__builtin_amdgcn_readlane((int)rec, 0) & 0xffff);
+        int i = 1;
+        while (i <= n) {
+            // Units i.. of the step until one asks for a flush (or the record ends).  Per unit: the batch turn every fourth unit
+            // (wait for the buffer coming into use, refill the one released), the unit's (value, ring row) pairs out of the batch
+            // registers, handed to the other quad of each slot, four ring rows requested, and per ring row as it arrives two
+            // fused multiply-adds into the group's partial sums: the same chain of fused multiply-adds, in column order, as
+            // the row-gather kernel.
+            int code, t0, t1;
+            asm volatile(
+                "s_waitcnt lgkmcnt(0)\n"
+                "loop_%=:\n\t"
+                "s_lshr_b32 %[t0], %[i], 1\n\t"
+                "v_readlane_b32 %[code], %[rec], %[t0]\n\t"
+                "s_lshl_b32 %[t0], %[i], 4\n\t"
+                "s_and_b32 %[t0], %[t0], 16\n\t"
+                "s_lshr_b32 %[code], %[code], %[t0]\n\t"
+                "s_and_b32 %[code], %[code], 0xffff\n\t"
+                "s_add_u32 %[i], %[i], 1\n\t"
+                "s_bitcmp1_b32 %[code], 7\n\t"
+                "s_cbranch_scc1 tail_%=\n\t"
+                // batch turn
+                "s_and_b32 %[t0], %[ub], 3\n\t"
+                "s_cmp_lg_u32 %[t0], 0\n\t"
+                "s_cbranch_scc1 noturn_%=\n\t"
+                "s_cmp_lt_u32 %[tss], 5\n\t"
+                "s_cbranch_scc1 w13_%=\n\t"
+                "s_waitcnt vmcnt(8)\n\t"
+                "s_branch wd_%=\n"
+                "w13_%=: s_waitcnt vmcnt(13)\n"
+                "wd_%=:\n\t"
+                "s_add_u32 %[tss], %[tss], 1\n\t"
+                "s_lshr_b32 %[t0], %[ub], 2\n\t"
+                "s_cmp_eq_u32 %[t0], 0\n\ts_cbranch_scc1 rq0_%=\n\t"
+                "s_cmp_eq_u32 %[t0], 1\n\ts_cbranch_scc1 rq1_%=\n\t"
+                "s_cmp_eq_u32 %[t0], 2\n\ts_cbranch_scc1 rq2_%=\n\t"
+                "s_cmp_eq_u32 %[t0], 3\n\ts_cbranch_scc1 rq3_%=\n\t"
+                "s_cmp_eq_u32 %[t0], 4\n\ts_cbranch_scc1 rq4_%=\n\t"
+                "global_load_dwordx4 v[240:243], %[voff], %[vb]\n\tglobal_load_dword v252, %[ooff], %[ob]\n\ts_branch rqd_%=\n\t"
+                RAILS_RQ(0, "v[244:247]", "v253") RAILS_RQ(1, "v[224:227]", "v248") RAILS_RQ(2, "v[228:231]", "v249")
+                RAILS_RQ(3, "v[232:235]", "v250") RAILS_RQ(4, "v[236:239]", "v251")
+                "rqd_%=:\n\t"
+                "v_add_u32 %[voff], 0x400, %[voff]\n\tv_add_u32 %[ooff], 0x100, %[ooff]\n"
+                "noturn_%=:\n\t"
+                // the unit's pairs: value registers v[224 + 2 (ub / 2) ..], 16-bit half (ub / 2) % 2 of v[248 + ub / 4]
+                "s_and_b32 %[t0], %[ub], -2\n\t"
+                "s_lshr_b32 %[t1], %[ub], 2\n\t"
+                "s_set_gpr_idx_on %[t0], 0x1\n\t"
+                "v_mov_b32 v220, v224\n\t"
+                "v_mov_b32 v221, v225\n\t"
+                "s_set_gpr_idx_on %[t1], 0x1\n\t"
+                "v_mov_b32 v222, v248\n\t"
+                "s_set_gpr_idx_off\n\t"
+                "s_lshl_b32 %[t0], %[ub], 3\n\t"
+                "s_and_b32 %[t0], %[t0], 16\n\t"
+                "v_bfe_u32 v222, v222, %[t0], 16\n\t"
+                "v_lshlrev_b32 v222, 7, v222\n\t"
+                // even units have them in the low quad of every slot, odd units in the high quad: hand them to the other quad
+                // (VALU write -> DPP read of the same register: two wait states)
+                "s_bitcmp1_b32 %[ub], 0\n\t"
+                "s_cbranch_scc1 odd_%=\n\t"
+                "s_nop 0\n\t"
+                "v_mov_b32_dpp v220, v220 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_mov_b32_dpp v221, v221 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_mov_b32_dpp v222, v222 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                "s_branch pd_%=\n"
+                "odd_%=:\n\t"
+                "s_nop 0\n\t"
+                "v_mov_b32_dpp v220, v220 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                "v_mov_b32_dpp v221, v221 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                "v_mov_b32_dpp v222, v222 row_shl:4 row_mask:0xf bank_mask:0x5\n"
+                "pd_%=:\n\t"
+                "s_add_u32 %[ub], %[ub], 1\n\t"
+                "s_cmp_eq_u32 %[ub], 24\n\t"
+                "s_cselect_b32 %[ub], 0, %[ub]\n\t"
+                "s_and_b32 %[t0], %[code], 63\n\t"
+                "s_lshl_b32 %[t0], %[t0], 2\n\t"
+                // four ring rows
+                "v_add_u32_dpp v223, v222, %[loff] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_u32_dpp v254, v222, %[loff] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "ds_read_b128 v[200:203], v223\n\t"
+                "ds_read_b128 v[204:207], v254\n\t"
+                "v_add_u32_dpp v223, v222, %[loff] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_u32_dpp v254, v222, %[loff] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "ds_read_b128 v[208:211], v223\n\t"
+                "ds_read_b128 v[212:215], v254\n\t"
+                // values of trips 0, 1 to every lane of the slot; multiply-adds as the rows arrive
+                "v_mov_b32_dpp v216, v220 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_mov_b32_dpp v217, v221 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_mov_b32_dpp v218, v220 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_mov_b32_dpp v219, v221 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "s_set_gpr_idx_on %[t0], 0xc\n\t"
+                "s_waitcnt lgkmcnt(3)\n\t"
+                "v_fma_f64 v[%c[acc]:%c[acc]+1], v[216:217], v[200:201], v[%c[acc]:%c[acc]+1]\n\t"
+                "v_fma_f64 v[%c[acc]+2:%c[acc]+3], v[216:217], v[202:203], v[%c[acc]+2:%c[acc]+3]\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_fma_f64 v[%c[acc]:%c[acc]+1], v[218:219], v[204:205], v[%c[acc]:%c[acc]+1]\n\t"
+                "v_fma_f64 v[%c[acc]+2:%c[acc]+3], v[218:219], v[206:207], v[%c[acc]+2:%c[acc]+3]\n\t"
+                "s_set_gpr_idx_off\n\t"
+                "v_mov_b32_dpp v216, v220 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_mov_b32_dpp v217, v221 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_mov_b32_dpp v218, v220 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_mov_b32_dpp v219, v221 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "s_set_gpr_idx_on %[t0], 0xc\n\t"
+                "s_waitcnt lgkmcnt(1)\n\t"
+                "v_fma_f64 v[%c[acc]:%c[acc]+1], v[216:217], v[208:209], v[%c[acc]:%c[acc]+1]\n\t"
+                "v_fma_f64 v[%c[acc]+2:%c[acc]+3], v[216:217], v[210:211], v[%c[acc]+2:%c[acc]+3]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_fma_f64 v[%c[acc]:%c[acc]+1], v[218:219], v[212:213], v[%c[acc]:%c[acc]+1]\n\t"
+                "v_fma_f64 v[%c[acc]+2:%c[acc]+3], v[218:219], v[214:215], v[%c[acc]+2:%c[acc]+3]\n\t"
+                "s_set_gpr_idx_off\n"
+                "tail_%=:\n\t"
+                "s_bitcmp1_b32 %[code], 6\n\t"
+                "s_cbranch_scc1 out_%=\n\t"
+                "s_cmp_le_u32 %[i], %[n]\n\t"
+                "s_cbranch_scc1 loop_%=\n\t"
+                "s_mov_b32 %[code], 0\n"
+                "out_%=:"
+                : [i] "+s"(i), [ub] "+s"(ub), [tss] "+s"(tss), [voff] "+v"(voff), [ooff] "+v"(ooff), [code] "=&s"(code), [t0] "=&s"(t0), [t1] "=&s"(t1)
+                : [rec] "v"(rec), [n] "s"(n), [loff] "v"(lane_off), [vb] "s"(vb), [ob] "s"(ob), [acc] "n"(SWEEP_ACC0)
+                : "memory", "scc", "m0");
+            if (code & 0x40) {
+                // the group's block is done: its partial sums go to Y and start again from zero
+                int s0, s1, s2, s3;
+                asm volatile("s_set_gpr_idx_on %4, 0x1\n\tv_mov_b32 %0, v%c5\n\tv_mov_b32 %1, v%c6\n\tv_mov_b32 %2, v%c7\n\tv_mov_b32 %3, v%c8\n\t"
+                             "s_set_gpr_idx_on %4, 0x8\n\tv_mov_b32 v%c5, 0\n\tv_mov_b32 v%c6, 0\n\tv_mov_b32 v%c7, 0\n\tv_mov_b32 v%c8, 0\n\t"
+                             "s_set_gpr_idx_off"
+                             : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+                             : "s"((code & 63) * 4), "n"(SWEEP_ACC0), "n"(SWEEP_ACC0 + 1), "n"(SWEEP_ACC0 + 2), "n"(SWEEP_ACC0 + 3)
+                             : "m0");
                 const int64_t row = (int64_t)__builtin_amdgcn_readfirstlane(fp[fl++]) + slot;
-                if (row < row_end) *reinterpret_cast<double2_t *>(Y + row * a.ldy + col0 + q * 2) = acc[g];
-                acc[g] = (double2_t){0.0, 0.0};
+                if (row < row_end) {
+                    double2_t out;
+                    out.x = __hiloint2double(s1, s0);
+                    out.y = __hiloint2double(s3, s2);
+                    *reinterpret_cast<double2_t *>(Y + row * a.ldy + col0 + q * 2) = out;
+                }
             }
         }
     }
@@ -202,7 +282,7 @@ struct DevPlan {
     rails_sweep_plan host; // kept for its small arrays and statistics (the big arrays are released after the upload)
     int64_t *part_row0 = nullptr, *sweep0 = nullptr, *hdr_off = nullptr, *batch_off = nullptr, *flush_off = nullptr;
     int32_t *nsteps = nullptr, *flush_rows = nullptr;
-    uint8_t *codes = nullptr;
+    uint16_t *codes = nullptr;
     double *vals = nullptr;
     uint16_t *offs = nullptr;
     bool ok = false;
@@ -288,7 +368,7 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
             RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
             std::vector<double>().swap(d->host.vals);
             std::vector<uint16_t>().swap(d->host.offs);
-            std::vector<uint8_t>().swap(d->host.codes);
+            std::vector<uint16_t>().swap(d->host.codes);
             d->ok = true;
         }
     }

@@ -84,28 +84,29 @@ bool schedule_group(const Ctx &c, int phase, int wave, int g, GroupSchedule &out
         const int64_t hi = (int64_t)(k + 1) * SEG;
         const int64_t lo = (int64_t)(k - NSEG + 2) * SEG;                            // readable: [lo, hi)
         const int64_t lo_next = (k == c.nsteps - 1) ? INT64_MAX : lo + SEG;          // gone after this step
-        int forced = 0, remaining = 0;
+        int forced = 0, remaining = 0, ready = INT_MAX;
         bool all_available = true;
         for (int s = 0; s < SLOTS; ++s) {
-            int f = 0;
+            int f = 0, av = 0;
             for (int64_t q = p[s]; q < pe[s]; ++q) {
                 const int64_t pos = (int64_t)c.col[q] - c.sweep0;
                 if (pos < lo) {
                     why = "a nonzero lost its X row before it was consumed (columns of a row not sorted?)";
                     return false;
                 }
-                if (pos < lo_next)
-                    ++f;
-                else
-                    break;
+                if (pos >= hi) break;
+                ++av;
+                if (pos < lo_next) ++f;
             }
             forced = std::max(forced, f);
+            if (pe[s] > p[s]) ready = std::min(ready, av);
             remaining = std::max<int>(remaining, (int)(pe[s] - p[s]));
             if (pe[s] > p[s] && (int64_t)c.col[pe[s] - 1] - c.sweep0 >= hi) all_available = false;
         }
         // the block has to be done before the first X row of the workgroup's next block leaves the ring
         const bool must_finish = next_first != INT64_MAX && (int64_t)k >= next_first + NSEG - 3;
-        int T = forced;
+        // what has to go now, or more where every slot with work left can fill whole units (no idle slots: spreads bursts for free)
+        int T = std::max(forced, ready == INT_MAX ? 0 : ready / 4 * 4);
         if (must_finish || remaining == 0) {
             if (!all_available) {
                 why = "the column window of a row block is wider than (phases - 1) blocks";
@@ -178,7 +179,7 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
     plan.ncols = ncols;
     plan.nnz = rowptr[m];
     const int W = prm.waves, G = prm.groups, P = prm.phases, SEG = prm.seg_rows;
-    if (W < 1 || G < 1 || G > RAILS_SWEEP_CODES || P < 1 || prm.parts < 1 || prm.nseg < 3 || SEG < 8 || SEG % 8 || (int64_t)SEG * prm.nseg > 65536) {
+    if (W < 1 || G < 1 || G > 64 || P < 1 || prm.parts < 1 || prm.nseg < 3 || SEG < 8 || SEG % 8 || (int64_t)SEG * prm.nseg > 65536) {
         plan.why = "bad parameters";
         return false;
     }
@@ -220,7 +221,8 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
         c.sweep0 = cmin;
         // at least one step per block of a workgroup, so that blocks of rows without nonzeros still get their zeros written
         const int64_t by_blocks = (c.nblocks + P - 1) / P;
-        c.nsteps = (int)std::max<int64_t>((cmax - cmin) / SEG + 1, by_blocks);
+        // NSEG - 2 steps beyond the last X row, so that the last nonzeros are consumed at the pace of all the others
+        c.nsteps = (int)std::max<int64_t>((cmax - cmin) / SEG + 1 + (prm.nseg - 2), by_blocks);
         plan.sweep0[x] = c.sweep0;
         plan.nsteps[x] = c.nsteps;
         staged += (int64_t)c.nsteps * SEG * P;
@@ -229,21 +231,31 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                 const int64_t prog = ((int64_t)x * P + ph) * W + w;
                 for (int g = 0; g < G; ++g)
                     if (!schedule_group(c, ph, w, g, gs[g], plan.why)) return false;
-                // serialise: per step a fixed-size record of RAILS_SWEEP_CODES bytes, byte g = units of four trips | flush << 7;
-                // the trips in (step, group) order, 16 trips per batch: lane q of a slot holds trips q and q + 8 of the batch
+                // serialise: per step a record of RAILS_SWEEP_CODES 16-bit entries: [0] = n, then one entry per unit of four trips (or per
+                // flush without trips): group | flush after << 6 | no trips << 7, in group order; the trips in the same order, 16
+                // trips per batch: lane q of a slot holds trips q and q + 8 of the batch
                 plan.hdr_off[prog] = (int64_t)plan.codes.size();
-                plan.codes.resize(plan.codes.size() + (size_t)c.nsteps * RAILS_SWEEP_CODES, (uint8_t)0);
-                uint8_t *h = plan.codes.data() + plan.hdr_off[prog];
+                plan.codes.resize(plan.codes.size() + (size_t)c.nsteps * RAILS_SWEEP_CODES, (uint16_t)0);
+                uint16_t *h = plan.codes.data() + plan.hdr_off[prog];
                 plan.batch_off[prog] = (int64_t)(plan.vals.size() / 128);
                 plan.flush_off[prog] = (int64_t)plan.flush_rows.size();
                 std::vector<size_t> tp(G, 0), fp(G, 0); // per group: next trip / next flush
                 int64_t trip = 0;                       // trips of this wave so far
-                for (int k = 0; k < c.nsteps; ++k)
+                for (int k = 0; k < c.nsteps; ++k) {
+                    int n = 0;
+                    uint16_t *rec = h + (size_t)k * RAILS_SWEEP_CODES;
                     for (int g = 0; g < G; ++g) {
                         const uint8_t code = gs[g].count[k];
-                        h[(size_t)k * RAILS_SWEEP_CODES + g] = code;
-                        const int T = 4 * (code & 0x7f);
-                        for (int t = 0; t < T; ++t, ++trip) {
+                        if (!code) continue;
+                        const int units = code & 0x7f;
+                        const bool flush = (code & 0x80) != 0;
+                        if (n + std::max(units, 1) > RAILS_SWEEP_CODES - 1) {
+                            plan.why = "more than 127 units of one wave in one step (step " + std::to_string(k) + " of " + std::to_string(c.nsteps) + ", part " + std::to_string(x) + ")";
+                            return false;
+                        }
+                        if (units == 0) rec[1 + n++] = (uint16_t)(g | 0x40 | 0x80);
+                        for (int u = 0; u < units; ++u) rec[1 + n++] = (uint16_t)(g | ((flush && u == units - 1) ? 0x40 : 0));
+                        for (int t = 0; t < 4 * units; ++t, ++trip) {
                             const int64_t b = plan.batch_off[prog] + trip / 16;
                             if ((size_t)(b + 1) * 128 > plan.vals.size()) {
                                 plan.vals.resize((size_t)(b + 1) * 128, 0.0);
@@ -256,14 +268,16 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                             }
                             ++tp[g];
                         }
-                        if (code & 0x80) plan.flush_rows.push_back(gs[g].flush[fp[g]++]);
+                        if (flush) plan.flush_rows.push_back(gs[g].flush[fp[g]++]);
                     }
+                    rec[0] = (uint16_t)n;
+                }
                 plan.trips += trip;
             }
     }
-    // spare batches at the very end: the kernel prefetches ahead of the trips it runs
-    plan.vals.resize(plan.vals.size() + 4 * 128, 0.0);
-    plan.offs.resize(plan.offs.size() + 4 * 128, 0);
+    // spare batches at the very end: the kernel requests batches up to six ahead of the trips it runs
+    plan.vals.resize(plan.vals.size() + 8 * 128, 0.0);
+    plan.offs.resize(plan.offs.size() + 8 * 128, 0);
     plan.entries = plan.nnz;
     plan.efficiency = plan.trips ? (double)plan.nnz / (8.0 * (double)plan.trips) : 1.0;
     plan.staged_rows_per_row = m ? (double)staged / (double)m : 0.0;

@@ -26,7 +26,7 @@
 #include <string>
 #include <vector>
 
-constexpr int RAILS_SWEEP_CODES = 64; // bytes per (program, step) record: one byte per lane of a wave; groups <= 64
+constexpr int RAILS_SWEEP_CODES = 128; // 16-bit entries per (program, step) record: two per lane of a wave; groups <= 64
 
 struct rails_sweep_params {
     int waves = 8;      // W: waves per workgroup
@@ -47,7 +47,8 @@ struct rails_sweep_plan {
     std::vector<int64_t> hdr_off;            // [programs] offset into codes
     std::vector<int64_t> batch_off;          // [programs] first batch (16 trips) in vals / offs
     std::vector<int64_t> flush_off;          // [programs] offset into flush_rows
-    std::vector<uint8_t> codes;              // per (program, step) RAILS_SWEEP_CODES bytes: byte g = units of 4 trips | flush << 7
+    std::vector<uint16_t> codes;             // per (program, step) RAILS_SWEEP_CODES entries: [0] = n, then n units of four trips:
+                                             // group | flush after << 6 | no trips << 7, in group order
     std::vector<double> vals;                // per batch of 16 trips: [slot 8][trip % 8][trip / 8]
     std::vector<uint16_t> offs;              // same indexing: ring row of the X row to read
     std::vector<int32_t> flush_rows;         // first row (of the wave's 8 x G rows: + g * 64 * ... see kernel) per flush

@@ -9,7 +9,7 @@ import numpy as np
 from . import _lib
 
 _ARRAYS = [("part_row0", np.int64), ("sweep0", np.int64), ("nsteps", np.int32), ("hdr_off", np.int64), ("batch_off", np.int64),
-           ("flush_off", np.int64), ("codes", np.uint8), ("vals", np.float64), ("offs", np.uint16), ("flush_rows", np.int32)]
+           ("flush_off", np.int64), ("codes", np.uint16), ("vals", np.float64), ("offs", np.uint16), ("flush_rows", np.int32)]
 
 
 class SweepPlan:

@@ -73,7 +73,10 @@ def test_sweep_handles_ragged_rows_and_rows_without_entries(ctx, oracle):
     rowptr[1:] = np.cumsum(cnt)
     col = np.empty(rowptr[-1], dtype=np.int32)
     for i in range(m):
-        col[rowptr[i]:rowptr[i + 1]] = np.sort(np.clip(i + g.integers(-3000, 3000, cnt[i]), 0, m - 1))
+        c = i + g.integers(-3000, 3000, cnt[i])
+        c = np.where(c < 0, -c, c)
+        c = np.where(c >= m, 2 * (m - 1) - c, c)  # reflected at the ends (clipping would pile dozens of entries of a row on one column)
+        col[rowptr[i]:rowptr[i + 1]] = np.sort(c)
     val = g.uniform(-1, 1, col.size)
     op = rails_amd.HipOperatorWrapper(ctx, rowptr, col, val)
     Xh, X, Y, outp = _panels(ctx, m, 128, seed=3)
