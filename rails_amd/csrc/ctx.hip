@@ -49,6 +49,7 @@ extern "C" int rails_ctx_create(int device, void *stream, rails_ctx **out)
     RAILS_HIP_CHECK(hipEventCreate(&c->ev0));
     RAILS_HIP_CHECK(hipEventCreate(&c->ev1));
     RAILS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
+    rails_host_lapack_init(nullptr); // load the host LAPACK now (not inside the first solve); its absence is reported by the calls that need it
     *out = c;
     return RAILS_OK;
 }

@@ -373,6 +373,7 @@ int rails_gram_dev(rails_ctx *c, const double *X, int ldx, const double *Y, int 
 extern "C" int rails_gram(rails_ctx *c, const rails_panel *X, int xc0, int a, const rails_panel *Y, int yc0, int b, double *C_host,
                           int ldc)
 {
+    rails_slow_guard slow__(c, "rails_gram", a, b);
     RAILS_REQUIRE(c && X && Y, "rails_gram: null argument");
     RAILS_REQUIRE(a >= 0 && b >= 0 && xc0 >= 0 && yc0 >= 0 && xc0 + a <= X->cap && yc0 + b <= Y->cap,
                   "rails_gram: windows [%d,%d) / [%d,%d) outside capacities %d / %d", xc0, xc0 + a, yc0, yc0 + b, X->cap, Y->cap);
@@ -420,6 +421,7 @@ int rails_panel_gemm_dev(rails_ctx *c, double alpha, const double *X, int ldx, i
 extern "C" int rails_panel_gemm_wide(rails_ctx *c, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc, int r,
                                      double beta, rails_panel *Y, int yc0)
 {
+    rails_slow_guard slow__(c, "rails_panel_gemm_wide", k, r);
     RAILS_REQUIRE(c && X && Y, "rails_panel_gemm_wide: null argument");
     RAILS_REQUIRE(k >= 0 && r >= 0 && xc0 >= 0 && yc0 >= 0 && xc0 + k <= X->cap && yc0 + r <= Y->cap,
                   "rails_panel_gemm_wide: windows [%d,%d) / [%d,%d) outside capacities %d / %d", xc0, xc0 + k, yc0, yc0 + r, X->cap, Y->cap);
@@ -448,6 +450,7 @@ extern "C" int rails_panel_gemm_wide(rails_ctx *c, double alpha, const rails_pan
 extern "C" int rails_panel_gemm(rails_ctx *c, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc,
                                 int r, double beta, rails_panel *Y, int yc0)
 {
+    rails_slow_guard slow__(c, "rails_panel_gemm", k, r);
     RAILS_REQUIRE(c && X && Y, "rails_panel_gemm: null argument");
     RAILS_REQUIRE(k >= 0 && r >= 0 && xc0 >= 0 && yc0 >= 0 && xc0 + k <= X->cap && yc0 + r <= Y->cap,
                   "rails_panel_gemm: windows [%d,%d) / [%d,%d) outside capacities %d / %d", xc0, xc0 + k, yc0, yc0 + r, X->cap, Y->cap);

@@ -84,7 +84,31 @@ void *lookup(void *h, const char *base)
 bool try_open(const std::string &path)
 {
     if (path.empty()) return false;
+    // OpenBLAS starts its worker threads when the library is loaded -- one per visible CPU (up to its build limit), each
+    // spinning for a while before it goes to sleep.  On a box whose CPU quota (cgroup) is far below its CPU count those ~60
+    // spinning threads use up the quota of a scheduling period in a few milliseconds and the WHOLE process is throttled for the
+    // rest of it: one 40-90 ms trip some 100 ms after the first host LAPACK call of a solve (BENCH_r01: "slowest 42 ms").
+    // openblas_set_num_threads() after the fact does not stop them, so the count is given through the environment for the
+    // duration of the dlopen (and restored: other BLAS users of the process keep their own setting).
+    int want_threads = 1;
+    if (const char *e = getenv("RAILS_LAPACK_THREADS")) want_threads = atoi(e) > 0 ? atoi(e) : 1;
+    static const char *thread_vars[] = {"OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", nullptr};
+    std::string saved[2];
+    bool had[2] = {false, false};
+    for (int i = 0; thread_vars[i]; ++i) {
+        if (const char *old = getenv(thread_vars[i])) {
+            had[i] = true;
+            saved[i] = old;
+        }
+        setenv(thread_vars[i], std::to_string(want_threads).c_str(), 1);
+    }
     void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    for (int i = 0; thread_vars[i]; ++i) {
+        if (had[i])
+            setenv(thread_vars[i], saved[i].c_str(), 1);
+        else
+            unsetenv(thread_vars[i]);
+    }
     if (!h) return false;
     HostLapack L;
     L.handle = h;

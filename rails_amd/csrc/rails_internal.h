@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -131,6 +132,41 @@ struct rails_csr {
     // operator given by its action (rails_csr_create_callback): rails_spmm hands the panels over
     rails_apply_fn apply_cb = nullptr;
     void *apply_user = nullptr;
+};
+
+// Diagnostics: with RAILS_TRACE_SLOW_MS=x every guarded entry point synchronises before and after its work and reports on stderr
+// when it took longer than x ms (finds the one call behind a slow trip; off by default: no synchronisation, no cost).
+struct rails_slow_guard {
+    rails_ctx *c;
+    const char *what;
+    long long a, b;
+    double t0 = 0.0;
+    static double limit_ms()
+    {
+        static const double v = getenv("RAILS_TRACE_SLOW_MS") ? atof(getenv("RAILS_TRACE_SLOW_MS")) : 0.0;
+        return v;
+    }
+    static double now()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    }
+    rails_slow_guard(rails_ctx *ctx, const char *w, long long a_ = 0, long long b_ = 0) : c(ctx), what(w), a(a_), b(b_)
+    {
+        if (limit_ms() > 0.0 && c) {
+            hipStreamSynchronize(c->stream);
+            t0 = now();
+        }
+    }
+    ~rails_slow_guard()
+    {
+        if (limit_ms() > 0.0 && c) {
+            hipStreamSynchronize(c->stream);
+            const double dt = now() - t0;
+            if (dt > limit_ms()) fprintf(stderr, "[rails slow] %s(%lld, %lld): %.2f ms\n", what, a, b, dt);
+        }
+    }
 };
 
 // ---- helpers implemented in ctx.hip ----

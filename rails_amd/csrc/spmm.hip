@@ -436,6 +436,7 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
 
 extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_panel *X, int xc0, int nc, rails_panel *Y, int yc0)
 {
+    rails_slow_guard slow__(c, "rails_spmm", nc, A ? A->m : 0);
     RAILS_REQUIRE(c && A && X && Y, "rails_spmm: null argument");
     RAILS_REQUIRE(xc0 >= 0 && nc >= 0 && xc0 + nc <= X->cap, "rails_spmm: X columns [%d,%d) outside capacity %d", xc0, xc0 + nc, X->cap);
     RAILS_REQUIRE(yc0 >= 0 && yc0 + nc <= Y->cap, "rails_spmm: Y columns [%d,%d) outside capacity %d", yc0, yc0 + nc, Y->cap);

@@ -158,7 +158,7 @@ struct SolverOps<HipOperatorWrapper, HipMultiVectorWrapper, HostDenseMatrix> {
     static int lanczos_fused(SolverT &solver, HipMultiVectorWrapper const &AV, HipMultiVectorWrapper const &MV, HostDenseMatrix const &T,
                              int max_iter, Lanczos &out)
     {
-        HipMultiVectorWrapper const &B = solver.B().vector();
+        HipMultiVectorWrapper const &B = solver.B().panel();
         HostDenseMatrix H(max_iter + 1, max_iter + 1);
         HostDenseMatrix Tc = T.copy(); // contiguous copy, also drops a transpose flag
         int steps = 0;
@@ -179,7 +179,7 @@ struct SolverOps<HipOperatorWrapper, HipMultiVectorWrapper, HostDenseMatrix> {
     static int lanczos_projected(SolverT &solver, State &st, HipMultiVectorWrapper const &AV, HipMultiVectorWrapper const &V,
                                  HostDenseMatrix const &T, HostDenseMatrix const &VAVm, HipMultiVectorWrapper const &BV, int L, Lanczos &out)
     {
-        HipMultiVectorWrapper const &B = solver.B().vector();
+        HipMultiVectorWrapper const &B = solver.B().panel();
         const int k = AV.N(), p = B.N(), kp = k + p;
         if (k <= 0 || V.N() != k || VAVm.M() != k || BV.N() != k || !BV.replicated()) return 1;
         // ---- Gram blocks AV'AV, AV'B (incremental), B'B (once) -----------------------------------------------
@@ -397,8 +397,8 @@ struct SolverOps<HipOperatorWrapper, HipMultiVectorWrapper, HostDenseMatrix> {
                        HostDenseMatrix const &VAV, HipMultiVectorWrapper const &BV, int max_iter, Lanczos &out)
     {
         out.ctx = AV.context();
-        bool can_fuse = !solver.B().is_matrix() && AV.N() <= 512 && solver.B().vector().N() <= 128 && ((AV.offset() | MV.offset()) & 1) == 0 &&
-                        (solver.B().vector().offset() & 1) == 0;
+        bool can_fuse = !solver.B().given_as_operator() && AV.N() <= 512 && solver.B().panel().N() <= 128 && ((AV.offset() | MV.offset()) & 1) == 0 &&
+                        (solver.B().panel().offset() & 1) == 0;
         if (!can_fuse) {
             HostDenseMatrix H(max_iter + 1, max_iter + 1);
             out.eigenvalues = HostDenseMatrix(max_iter, 1);

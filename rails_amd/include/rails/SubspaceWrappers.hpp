@@ -62,11 +62,14 @@ public:
     bool profile_sync = getenv("RAILS_SUBSPACE_PROFILE") != nullptr;
     bool trace = getenv("RAILS_SUBSPACE_TRACE") != nullptr;
     double reorth_survival = getenv("RAILS_SUBSPACE_REORTH") ? atof(getenv("RAILS_SUBSPACE_REORTH")) : 0.5;
+    // RAILS_SUBSPACE_SLOW_MS=x (with RAILS_SUBSPACE_PROFILE): one line on stderr for every part that took longer than x ms
+    double slow_ms = getenv("RAILS_SUBSPACE_SLOW_MS") ? atof(getenv("RAILS_SUBSPACE_SLOW_MS")) : 0.0;
     struct Tick {
         SubspaceBasis *b;
         double *acc;
+        const char *what;
         std::chrono::steady_clock::time_point t0;
-        Tick(SubspaceBasis *bb, double *a) : b(bb), acc(a)
+        Tick(SubspaceBasis *bb, double *a, const char *w = "") : b(bb), acc(a), what(w)
         {
             if (b->profile_sync) rails_ctx_sync(b->ctx);
             t0 = std::chrono::steady_clock::now();
@@ -74,7 +77,10 @@ public:
         ~Tick()
         {
             if (b->profile_sync) rails_ctx_sync(b->ctx);
-            *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            *acc += dt;
+            if (b->slow_ms > 0.0 && dt * 1e3 > b->slow_ms)
+                std::cerr << "[subspace] " << what << ": " << dt * 1e3 << " ms (dim " << b->dim << ", absorbs so far " << b->n_absorb << ")" << std::endl;
         }
     };
     // The next 1-column random() of the solver (the Lanczos start vector of the coming trip, src/LyapunovSolver.hpp:374) is
@@ -137,7 +143,7 @@ public:
         HipMultiVectorWrapper out;
         out = scratch; // shares the panel
         n_materialise++;
-        Tick tick(this, &t_materialise);
+        Tick tick(this, &t_materialise, "materialise");
         if (n <= 0) return out;
         if (dim == 0) {
             out = 0.0;
@@ -170,7 +176,7 @@ public:
         n_absorb++;
         n_absorb_cols += w;
         if (w <= 0) return true;
-        Tick tick(this, &t_absorb);
+        Tick tick(this, &t_absorb, "absorb");
         const int ld = row_cap;
         rails_panel *pp = P.panel();
         // one Gram call per round gives both the projections P'X (first dim rows) and the block's own Gram matrix X'X (last w rows):
@@ -393,7 +399,7 @@ public:
         std::vector<double> Q((size_t)dim * std::min(dim, ncols));
         int rank = 0, info = 0;
         {
-            Tick tick(this, &t_qr);
+            Tick tick(this, &t_qr, "compress: pivoted QR");
             rails_range_basis(dim, ncols, Call.data(), dim, 1e-14, Q.data(), dim, &rank, &info);
         }
         if (info != 0 || rank <= 0 || rank >= dim - 8) return; // nothing (worth it) to drop
@@ -404,13 +410,13 @@ public:
         }
         P2.resize(rank);
         {
-            Tick rot(this, &t_rotate);
+            Tick rot(this, &t_rotate, "compress: rotation");
             if (!hip_ok(rails_panel_gemm_wide(ctx, 1.0, P.panel(), 0, dim, Q.data(), dim, rank, 0.0, P2.panel(), 0), "rails_panel_gemm_wide")) {
                 failed = true;
                 return;
             }
         }
-        Tick tick(this, &t_recoef);
+        Tick tick(this, &t_recoef, "compress: coefficients");
         // host: C <- Q' C (columns up to the last non-zero one of every store)
         for (auto &s : stores) {
             int used = 0;
