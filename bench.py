@@ -15,8 +15,9 @@ cost of a trip does not depend on it); W warm-up trips run first, then EXACTLY K
 barrier + synchronize on both sides, MAX over ranks.
 
 One JSON line on rank 0 with `roofline` (the CSR x tall-skinny A*V kernel at k = 128 columns, timed live
-with HIP events on the library's stream) and `cpu_baseline` (the CPU oracle, kind "port", on a bounded
-sample of the same workload, rank 0 at N = 1 only).
+with HIP events on the library's stream) and `cpu_baseline` (the CPU oracle, kind "port", on the same
+full-size workload for a bounded number of trips timed one by one, rank 0 at N = 1 only); `config` also
+carries the rate of the direct back end on the same workload (`direct_backend_it_s`, a short run of its own).
 """
 import argparse
 import json
@@ -105,7 +106,9 @@ def main():
     ap.add_argument("--spmm-reps", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-rows", type=int, default=125000, help="rows of the bounded CPU sample")
+    ap.add_argument("--cpu-trips", type=int, default=3, help="cpu_baseline: trips of the full-size CPU run that are timed")
+    ap.add_argument("--cpu-warmup", type=int, default=5, help="cpu_baseline: trips of the full-size CPU run before the timed ones (at most --warmup)")
+    ap.add_argument("--direct-steps", type=int, default=8, help="timed trips of the extra run on the direct back end (0: skip it)")
     ap.add_argument("--spmm-variant", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend; gloo = rehearsal of the multi-process path "
@@ -211,6 +214,7 @@ def main():
         A.apply(X, Y)
     spmm_ms = ctx.timer_stop() / args.spmm_reps
     spmm_kernel = A.last_kernel()
+    sweep_stats = A.sweep_stats(kk) if spmm_kernel == "k_spmm_sweep" else None
     # algorithmic bytes per launch: nnz*(8+4) + (m+1)*4 + 2*m*k*8
     alg_bytes = nnz_local * 12 + (ml + 1) * 4 + 2 * ml * kk * 8
     achieved = alg_bytes / (spmm_ms * 1e-3) / 1e9
@@ -267,6 +271,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     its = K / elapsed
+    import ctypes as _C
+
+    _sm, _bs = _C.c_long(0), _C.c_long(0)
+    rails_amd.load().rails_sb03md_counts(_C.byref(_sm), _C.byref(_bs))
+    sb_counts = (int(_sm.value), int(_bs.value))
     hist = solver.history()
     log("[rank %d] host sections (s, whole solve incl. warm-up): %s" % (rank, json.dumps(solver.profile())))
     if len(stamps) > W + 2:
@@ -277,40 +286,67 @@ def main():
     log("[rank %d] counters: %s %s" % (rank, json.dumps(ctx.stats()), json.dumps(solver.backend_stats())))
     log("[rank %d] %d trips in %.3fs -> %.2f it/s; Lanczos estimates %.3e -> %.3e; V.N()=%d" % (rank, K, elapsed, its, hist[0], hist[-1], solver.k))
 
-    # ---- cpu_baseline: the oracle (port of the Stl path) on a bounded sample, rank 0, N = 1 ---------------
+    # ---- the direct back end (device panels for V and AV: fused one-pass Lanczos kernel, block orthogonalisation on MFMA -- the north
+    # star's literal path) on the same workload, a short timed run of its own: config.direct_backend_it_s ---------------------------
+    direct_its = None
+    if args.subspace and args.direct_steps > 0:
+        Wd, Kd = min(W, 4), args.direct_steps
+        marks_d = {}
+        solver.set_option("subspace", 0)
+        solver.set_option("max_trips", Wd + Kd)
+
+        def on_trip_direct(trip):
+            if trip == Wd or trip == Wd + Kd:
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                marks_d[trip] = time.perf_counter()
+
+        solver.set_trip_callback(on_trip_direct)
+        gc.disable()
+        try:
+            solver.solve(fetch=False)
+        finally:
+            gc.enable()
+        if Wd in marks_d and Wd + Kd in marks_d:
+            dt = marks_d[Wd + Kd] - marks_d[Wd]
+            if dist is not None:
+                t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            direct_its = Kd / dt
+            log("[rank %d] direct back end: %d trips in %.3fs -> %.2f it/s; counters %s" % (rank, Kd, dt, direct_its, json.dumps(ctx.stats())))
+
+    # ---- cpu_baseline: the oracle (CPU restatement of the Stl path, OpenMP) on the SAME full-size workload, rank 0, N = 1: a bounded
+    # number of trips, each timed on its own (no extrapolation) -------------------------------------------------------------------
     cpu = None
     if rank == 0 and nranks == 1 and not args.no_cpu:
         from oracle.oracle import Oracle
         from rails_amd import problems as P
 
         orc = Oracle()
-        ms = min(args.cpu_rows, ml)
         if args.pattern == "banded":
-            As = P.banded_random(ms, 27, min(args.bandwidth, ms // 4), seed=args.seed)
+            As = P.banded_random(ml, 27, args.bandwidth, seed=args.seed)
         elif args.pattern == "stencil27":
-            n = round(ms ** (1.0 / 3.0))
-            ms = n * n * n
+            n = round(ml ** (1.0 / 3.0))
             As = P.stencil27(n, n, n, random_values=True, seed=args.seed)
         elif args.pattern == "laplace7":
-            As = P.laplace7(50, 50, max(1, ms // 2500))
-            ms = As[0].size - 1
+            As = P.laplace7(50, 50, max(1, ml // 2500))
         else:
-            As = P.uniform_random(ms, 27, seed=args.seed)
-        Bs = P.rhs(ms, args.p, seed=args.seed + 7)
-        trips_cpu = W + min(K, 10)
-        prm = orc.params({**params, "rng_mode": 1, "seed": args.seed, "max_trips": trips_cpu})
-        t0 = time.perf_counter()
-        outw = orc.solve(As, Bs, orc.params({**params, "rng_mode": 1, "seed": args.seed, "max_trips": W}), vcap=args.restart + args.expand)
-        t1 = time.perf_counter()
-        out = orc.solve(As, Bs, prm, vcap=args.restart + args.expand)
-        t2 = time.perf_counter()
-        # time of the last (trips_cpu - W) trips = full run - warm-up-only run
-        dt = max((t2 - t1) - (t1 - t0), 1e-9)
-        its_cpu_sample = (trips_cpu - W) / dt
-        cpu = {"value": its_cpu_sample * ms / ml, "unit": "iterations/s", "cores": orc.num_threads(), "kind": "port",
-               "sample": "oracle (CPU restatement of the Stl path, OpenMP) on the same workload restricted to %d rows: trips %d..%d timed "
-                         "(%.2f it/s on the sample), scaled by %d/%d rows to the full size" % (ms, W + 1, trips_cpu, its_cpu_sample, ms, ml)}
-        log("[cpu] sample %d rows: %.2f it/s -> scaled %.3f it/s on %d threads" % (ms, its_cpu_sample, cpu["value"], orc.num_threads()))
+            As = P.uniform_random(ml, 27, seed=args.seed)
+        Bs = P.rhs(ml, args.p, seed=args.seed + 7)
+        Wc, Kc = min(W, args.cpu_warmup), args.cpu_trips
+        out = orc.solve(As, Bs, orc.params({**params, "rng_mode": 1, "seed": args.seed, "max_trips": Wc + Kc}), vcap=args.restart + args.expand)
+        ts = out["trip_seconds"]
+        if ts.size >= Wc + Kc and Wc >= 1:
+            dt = float(ts[Wc + Kc - 1] - ts[Wc - 1])
+            cpu = {"value": Kc / dt, "unit": "iterations/s", "cores": orc.num_threads(), "kind": "port", "extrapolated": False,
+                   "sample": "oracle (CPU restatement of the Stl path, OpenMP, %d threads of %d host CPUs) on the full workload (%d rows): trips %d..%d "
+                             "timed one by one after %d warm-up trips (%.2f s per trip; V has %d columns at the end)" % (
+                                 orc.num_threads(), os.cpu_count() or 0, ml, Wc + 1, Wc + Kc, Wc, dt / Kc, out["V"].shape[1])}
+            log("[cpu] full size, %d threads: trips %d..%d in %.2fs -> %.3f it/s" % (orc.num_threads(), Wc + 1, Wc + Kc, dt, cpu["value"]))
+        del out, As, Bs
 
     if rank == 0:
         line = {
@@ -325,9 +361,14 @@ def main():
                        "backend": "coordinates in a device-resident orthonormal basis" if args.subspace else "direct panels",
                        # one JOINT solve over n_gpus x m rows: under weak scaling the ideal is a constant iteration rate; the rate at which
                        # matrix rows are processed (rows x iterations / s) is the quantity that grows with the GPU count
-                       "global_rows": int(mg), "row_iterations_per_s": its * mg},
+                       "global_rows": int(mg), "row_iterations_per_s": its * mg,
+                       # the same workload on the direct back end (fused Lanczos kernel + block orthogonalisation), a short run of its own
+                       "direct_backend_it_s": direct_its,
+                       "host_projected_solve_routes": {"smith_or_adi": sb_counts[0], "bartels_stewart": sb_counts[1]}},
             "roofline": {"bound": "hbm", "kernel": spmm_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms,
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, corrected as profiles/README.md says)" if traffic else None,
+                         "schedule": sweep_stats},
             "cpu_baseline": cpu,
         }
         emit(line)

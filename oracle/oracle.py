@@ -315,8 +315,12 @@ class Oracle:
             _p(mva) if mva is not None else nulld,
             _p(B), m, p, C.byref(prm), _p(V), m, vcap, C.byref(k), _p(T), vcap, _p(hist), hist_cap, C.byref(trips))
         kk = k.value
+        ts = np.zeros(max(trips.value, 1))
+        self.lib.orc_trip_seconds.restype = C.c_int
+        self.lib.orc_trip_seconds.argtypes = [_dp, C.c_int]
+        nt = self.lib.orc_trip_seconds(_p(ts), ts.size)
         return dict(ret=ret, V=V[:, :kk].copy(order="F"), T=T[:kk, :kk].copy(order="F"), trips=trips.value,
-                    res_hist=hist[:min(trips.value, hist_cap)].copy())
+                    res_hist=hist[:min(trips.value, hist_cap)].copy(), trip_seconds=ts[:min(nt, ts.size)].copy())
 
 
 class Reference:

@@ -543,6 +543,9 @@ void project_small(int k, int r, const double *X, std::vector<double> &S, int &l
 // ----------------------------------------------------------------------------
 // C ABI used by tests/, smoke() and bench.py's cpu_baseline.
 // ----------------------------------------------------------------------------
+static std::vector<double> g_trip_seconds;
+static double g_solve_t0 = 0.0;
+
 extern "C" {
 
 struct orc_params {
@@ -595,6 +598,13 @@ void orc_set_partition(orc_allreduce_fn ar, orc_halo_fn halo, const int64_t *sen
     g_send_rows.assign(send_rows, send_rows + (send_rows ? n_send : 0));
     g_n_ghost = n_ghost;
     g_m_global = m_global;
+}
+// seconds since the start of the last orc_solve at which each of its trips had its residual estimate (timing of single trips)
+int orc_trip_seconds(double *out, int cap)
+{
+    int n = (int)g_trip_seconds.size();
+    for (int i = 0; i < n && i < cap; ++i) out[i] = g_trip_seconds[i];
+    return n;
 }
 int orc_num_threads() { return omp_get_max_threads(); }
 void orc_set_num_threads(int n) { omp_set_num_threads(n); }
@@ -692,6 +702,8 @@ int orc_solve(int m, const double *Adense, int lda, const int64_t *rp, const int
               double *res_hist, int hist_cap, int *trips_out)
 {
     if (orc_lapack_init(nullptr)) return -100;
+    g_trip_seconds.clear();
+    g_solve_t0 = omp_get_wtime();
     Op A;
     A.m = m;
     A.dense = Adense;
@@ -880,6 +892,8 @@ int orc_solve(int m, const double *Adense, int lda, const int64_t *rp, const int
         if (prm->verbose)
             printf("Iteration %d. Estimate Lanczos, absolute: %.6e, relative: %.6e (V.N=%d)\n", iter + 1, res,
                    std::abs(res) / r0 / r0, kV);
+
+        g_trip_seconds.push_back(omp_get_wtime() - g_solve_t0); // bench.py's cpu_baseline: when each trip's estimate was ready
 
         bool converged = std::abs(res) < prm->tol * r0 * r0; // :223
         if (converged || iter + 1 >= prm->max_iter || kV >= n) { // :224-242

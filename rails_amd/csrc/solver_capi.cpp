@@ -218,6 +218,7 @@ extern "C" int rails_solver_solve(rails_solver *s, int *code, int *k)
     // a warm start needs the caller's V; "Restart from solution" without one is the direct back end's business (it starts from
     // the single column the solver object holds, like the reference)
     s->last_was_subspace = s->subspace && (s->have_V0 || !restart_from_solution);
+    rails::clear_sticky_error();
     int rc;
     if (s->last_was_subspace) {
         rc = solve_in_coordinates(s);
@@ -228,6 +229,12 @@ extern "C" int rails_solver_solve(rails_solver *s, int *code, int *k)
     if (code) *code = rc;
     if (k) *k = s->V.N();
     if (rails_ctx_sync(s->ctx) != RAILS_OK) return RAILS_EHIP;
+    // a library call that failed somewhere inside the wrappers (they only print, like the reference's): V and T are not to be trusted
+    if (rails::sticky_error() != RAILS_OK) {
+        const int err = rails::sticky_error();
+        rails_set_error("rails_solver_solve: a device operation failed during the solve (code %d, first failure; see stderr): %s", err, rails_last_error());
+        return err;
+    }
     return RAILS_OK;
 }
 

@@ -41,10 +41,22 @@ inline rails_ctx *&default_context()
 }
 inline void set_default_context(rails_ctx *ctx) { default_context() = ctx; }
 
+// The wrapper classes have the reference's error behaviour -- a message on stderr, no exception, a result that may be garbage
+// (src/StlWrapper.cpp:173-179) -- which a caller of solve() cannot see.  Every failed library call therefore also latches its
+// code here (first failure wins, per thread): rails_solver_solve() and C++ users check it after a solve (and may check it any
+// time), and turn a run on zero-filled or partial panels into an error return instead of a normal-looking result.
+inline int &sticky_error()
+{
+    static thread_local int code = RAILS_OK;
+    return code;
+}
+inline void clear_sticky_error() { sticky_error() = RAILS_OK; }
+
 inline bool hip_ok(int rc, const char *what)
 {
     if (rc != RAILS_OK) {
         std::cerr << "rails_amd: " << what << " failed (" << rc << "): " << rails_last_error() << std::endl;
+        if (sticky_error() == RAILS_OK) sticky_error() = rc;
         return false;
     }
     return true;
@@ -254,7 +266,8 @@ public:
                 hcap_ = ncap;
             }
         } else if (panel_) {
-            if (c0_ + n > rails_panel_capacity(panel_->p)) hip_ok(rails_panel_reserve(ctx_, panel_->p, c0_ + n), "rails_panel_reserve");
+            if (c0_ + n > rails_panel_capacity(panel_->p) && !hip_ok(rails_panel_reserve(ctx_, panel_->p, c0_ + n), "rails_panel_reserve"))
+                n = std::max(0, rails_panel_capacity(panel_->p) - c0_); // the failure is latched (sticky_error); stay inside the panel
         } else if (m_ >= 0) {
             panel_ = std::make_shared<PanelHandle>(ctx_, m_, std::max(n, 1));
         }
@@ -367,7 +380,9 @@ public:
                     out.hdata()[r + (size_t)j * m_] = s;
                 }
         } else
-            hip_ok(rails_panel_gemm(ctx_, 1.0, panel_->p, c0_, n_, (double *)C, C.LDA(), C.N(), 0.0, out.panel_->p, 0), "rails_panel_gemm");
+            // more than 256 output columns (a restart that keeps that many vectors): the sliced form; `out` is a panel of its own
+            hip_ok((C.N() > 256 ? rails_panel_gemm_wide : rails_panel_gemm)(ctx_, 1.0, panel_->p, c0_, n_, (double *)C, C.LDA(), C.N(), 0.0, out.panel_->p, 0),
+                   "rails_panel_gemm");
         return out;
     }
 
@@ -392,7 +407,8 @@ public:
             return out;
         }
         if (o.n_ > 0)
-            hip_ok(rails_panel_gemm(ctx_, 1.0, panel_->p, c0_, n_, o.hdata(), (int)o.m_, o.n_, 0.0, out.panel_->p, 0), "rails_panel_gemm");
+            hip_ok((o.n_ > 256 ? rails_panel_gemm_wide : rails_panel_gemm)(ctx_, 1.0, panel_->p, c0_, n_, o.hdata(), (int)o.m_, o.n_, 0.0, out.panel_->p, 0),
+                   "rails_panel_gemm");
         return out;
     }
 

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "rails/HipSolverOps.hpp"
@@ -783,6 +784,92 @@ static void dense_cases()
     }
 }
 
+// The solver template on the HIP classes against the reference's 2 x 2 known answers, with B given as an operator and as a panel
+// (test/LyapunovSolverEpetra_test.cpp:109-177 and :179-239: A = [0 1; -5 -5]; B = -I gives X = [0.62 -0.5; -0.5 0.6], B = [-1; -1]
+// gives X = [0.82 -0.5; -0.5 0.6], both to 1e-14 there), and what happens to a failed library call inside the wrappers.
+struct KatParameters {
+    std::map<std::string, double> p;
+    template <typename T>
+    T get(std::string const &name, T def)
+    {
+        auto it = p.find(name);
+        return it == p.end() ? def : (T)it->second;
+    }
+};
+
+template <class SolverT, class MV>
+static void check_kat(SolverT &solver, MV &V, double x00, double x01, double x11)
+{
+    KatParameters params;
+    params.p = {{"Minimize solution space", 0.0}, {"Lanczos iterations", 10.0}, {"Expand size", 3.0}};
+    CHECK(solver.set_parameters(params) == 0);
+    solver.set_verbose(false);
+    HostDenseMatrix T;
+    const int code = solver.solve(V, T);
+    CHECK(code == 0);
+    std::vector<double> h = host_of(V);
+    const int n = 2, k = V.N();
+    double X[2][2] = {{0, 0}, {0, 0}};
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            for (int a = 0; a < k; ++a)
+                for (int b = 0; b < k; ++b) X[i][j] += h[i + (size_t)a * n] * T(a, b) * h[j + (size_t)b * n];
+    CHECK_NEAR(x00, X[0][0], 1e-12);
+    CHECK_NEAR(x01, X[0][1], 1e-12);
+    CHECK_NEAR(x01, X[1][0], 1e-12);
+    CHECK_NEAR(x11, X[1][1], 1e-12);
+}
+
+static void solver_cases(rails_ctx *ctx)
+{
+    const int n = 2;
+    std::vector<double> Ad = {0.0, -5.0, 1.0, -5.0}; // column-major [0 1; -5 -5]
+    std::vector<double> minus_identity = {-1.0, 0.0, 0.0, -1.0};
+    HipOperatorWrapper A = op_from_dense(ctx, Ad, n);
+    {
+        g_case = "Solver.B as an operator (direct panels)";
+        rails::clear_sticky_error();
+        HipOperatorWrapper Bop = op_from_dense(ctx, minus_identity, n);
+        rails::HipSolver solver(A, Bop, A);
+        CHECK(solver.B().given_as_operator());
+        HipMultiVectorWrapper V(n, 1, ctx);
+        check_kat(solver, V, 0.62, -0.5, 0.6);
+        CHECK(rails::sticky_error() == RAILS_OK);
+    }
+    {
+        g_case = "Solver.B as a panel (direct panels)";
+        HipMultiVectorWrapper B(n, 1, ctx);
+        B = -1.0;
+        rails::HipSolver solver(A, B, A);
+        CHECK(!solver.B().given_as_operator());
+        HipMultiVectorWrapper V(n, 1, ctx);
+        check_kat(solver, V, 0.82, -0.5, 0.6);
+    }
+    {
+        g_case = "Solver.B as a panel (coordinates in a basis)";
+        auto basis = std::make_shared<SubspaceBasis>(ctx, n, n, 16);
+        HipMultiVectorWrapper B(n, 1, ctx);
+        B = -1.0;
+        SubspaceMultiVector Bc = SubspaceMultiVector::Absorb(basis, B);
+        SubspaceOperator Ac(A, basis);
+        rails::SubspaceSolver solver(Ac, Bc, Ac);
+        SubspaceMultiVector V(basis, 1);
+        check_kat(solver, V, 0.82, -0.5, 0.6);
+    }
+    {
+        // a library call that fails inside a wrapper prints (like the reference) AND latches its code: a caller of solve() can tell
+        g_case = "Wrappers.failed call is latched";
+        rails::clear_sticky_error();
+        HipMultiVectorWrapper huge(4000000, 1, ctx);
+        std::fprintf(stderr, "(the next message is expected: a 128 TB panel is requested on purpose)\n");
+        huge.resize(1 << 22);
+        CHECK(rails::sticky_error() == RAILS_ENOMEM);
+        CHECK(huge.N() <= huge.capacity()); // the column count stays inside what exists
+        rails::clear_sticky_error();
+        CHECK(rails::sticky_error() == RAILS_OK);
+    }
+}
+
 int main(int argc, char **argv)
 {
     bool host_only = argc > 1 && std::strcmp(argv[1], "--host") == 0;
@@ -809,6 +896,7 @@ int main(int argc, char **argv)
         }
         subspace_operator_cases(ctx);
         subspace_basis_cases(ctx);
+        solver_cases(ctx);
         rails_ctx_destroy(ctx);
     }
     std::printf("%s: %d checks, %d failures\n", host_only ? "host cases" : "all cases", g_checks, g_fail);
