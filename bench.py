@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend; gloo = rehearsal of the multi-process path "
                     "(collectives staged through host memory, all ranks may share one GPU with --one-device)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box, at most 6 ranks)")
+    ap.add_argument("--hooks", action="store_true", help="multi-GPU: exchange through the torch.distributed hooks instead of the library's own RCCL communicator")
     ap.add_argument("--force-hooks", action="store_true", help="single rank: still route every reduction through torch.distributed (RCCL, world size 1)")
     ap.add_argument("--projected-lanczos", type=int, default=0, help="1: coefficient-space residual Lanczos (rails/HipSolverOps.hpp)")
     ap.add_argument("--subspace", type=int, default=1, help="1 (default): coordinate-space back end (rails/SubspaceWrappers.hpp); 0: direct panels")
@@ -160,13 +161,28 @@ def main():
     assert stream, "expected a non-default stream handle"
     ctx = rails_amd.Context(device=local_rank, stream=stream, seed=args.seed)
     ctx.set_partition(rank, nranks, r0, mg)
+    collectives = "none (single GPU)"
     if nranks > 1:
         starts = np.arange(nranks + 1, dtype=np.int64) * ml
         plan = partition.HaloPlan(starts, rank, colg, partition.all_gather_object_fn())
         A = rails_amd.HipOperatorWrapper(ctx, rowptr, plan.col_local, val, ncols_ext=ml + plan.n_ghost)
         staged = args.backend != "nccl"
-        A.set_halo(plan, partition.make_halo(plan, on_device=True, host_staged=staged))
-        ctx.set_allreduce(partition.make_allreduce(on_device=True, host_staged=staged))
+        native = args.backend == "nccl" and not args.hooks
+        if native:
+            # the library's own RCCL communicator: the unique id travels over the torch.distributed group that is up already
+            try:
+                box = [rails_amd.Context.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ctx.init_rccl(box[0], nranks, rank)
+                A.set_halo(plan, None)
+                collectives = "RCCL inside the library (ncclAllReduce of the projected blocks, ncclSend/ncclRecv of the ghost rows)"
+            except Exception as e:  # fall back to the hooks rather than lose the run
+                log("[rank %d] native RCCL set-up failed (%s): using the torch.distributed hooks" % (rank, e))
+                native = False
+        if not native:
+            A.set_halo(plan, partition.make_halo(plan, on_device=True, host_staged=staged))
+            ctx.set_allreduce(partition.make_allreduce(on_device=True, host_staged=staged))
+            collectives = "torch.distributed hooks (%s)" % args.backend
         halo_rows = plan.n_ghost
     else:
         A = rails_amd.HipOperatorWrapper(ctx, rowptr, colg.astype(np.int32), val)
@@ -356,6 +372,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: m=%d rows/GPU (global %d), 27 nnz/row %s CSR, B m x %d, Restart size %d, Reduced size %d, "
                                    "Expand size %d, Lanczos iterations %d" % (ml, mg, desc, args.p, args.restart, args.reduced, args.expand, args.lanczos),
                        "parallelism": "row-partition x%d, RCCL all-reduce of projected blocks" % nranks if nranks > 1 else "single GPU",
+                       "collectives": collectives,
                        "spmm_columns": kk, "residual_lanczos": ("the reference's recurrence on coordinate vectors (host)" if args.subspace else
                                             ("coefficient-space, Gram differences" if args.projected_lanczos else "fused one-pass-per-step kernel")),
                        "backend": "coordinates in a device-resident orthonormal basis" if args.subspace else "direct panels",

@@ -85,6 +85,18 @@ int rails_ctx_set_partition(rails_ctx *ctx, int rank, int nranks, int64_t row0, 
 typedef int (*rails_allreduce_fn)(void *user, double *dev_buf, size_t n, void *stream);
 int rails_ctx_set_allreduce(rails_ctx *ctx, rails_allreduce_fn fn, void *user);
 
+/* The same all-reduce (and the ghost-row exchange of rails_spmm) done by the library itself over RCCL -- xGMI inside a node --
+ * on the context's stream, with no hook and no Python in the loop.  Either let the library make the communicator: rank 0 calls
+ * rails_rccl_unique_id, the application hands the RAILS_RCCL_ID_BYTES bytes to every rank (any way it likes: MPI, files, a
+ * torch.distributed broadcast), then EVERY rank calls rails_ctx_init_rccl (collective; device = the context's); or adopt one
+ * the application already has (an ncclComm_t; the caller keeps ownership).  A hook installed with rails_ctx_set_allreduce
+ * takes precedence.  librccl.so.1 is loaded at run time (RAILS_RCCL_LIB overrides the name). */
+#define RAILS_RCCL_ID_BYTES 128
+int rails_rccl_unique_id(void *id_out);
+int rails_ctx_init_rccl(rails_ctx *ctx, const void *id, int nranks, int rank);
+int rails_ctx_set_rccl(rails_ctx *ctx, void *nccl_comm);
+int rails_ctx_rccl_size(const rails_ctx *ctx); /* ranks of the communicator, 0 without one */
+
 /* Halo hook for the row-partitioned operator apply: given the packed rows this rank
  * must send (send_buf, concatenated per destination rank as described by the counts
  * passed to rails_csr_set_halo) fill recv_buf with the ghost rows, on `stream`.
@@ -114,6 +126,11 @@ int64_t rails_csr_nnz(const rails_csr *A);
  * the order the halo hook expects), n_ghost rows are received. */
 int rails_csr_set_halo(rails_csr *A, int64_t n_send, const int64_t *send_rows, int64_t n_ghost,
                        rails_halo_fn fn, void *user);
+
+/* Rows per neighbour rank of that plan: send_rows is grouped by destination rank (ranks ascending, send_counts[r] rows to rank r) and
+ * the ghost rows by owning rank (recv_counts[r] from rank r).  With these and an RCCL communicator on the context the exchange
+ * is one group of ncclSend / ncclRecv per product and rails_csr_set_halo may be called with fn = NULL. */
+int rails_csr_set_halo_counts(rails_csr *A, int nranks, const int64_t *send_counts, const int64_t *recv_counts);
 
 /* Y[:, yc0:yc0+nc] = op(A) * X[:, xc0:xc0+nc]; trans != 0 applies A^T (single GPU only).
  * Replaces `A_ * W` (src/LyapunovSolver.hpp:146).  X and Y must not alias. */

@@ -33,6 +33,11 @@ SIGNATURES = {
     "rails_ctx_rng_state": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rails_ctx_set_partition": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int64, C.c_int64]),
     "rails_ctx_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
+    "rails_rccl_unique_id": (C.c_int, [_vp]),
+    "rails_ctx_init_rccl": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "rails_ctx_set_rccl": (C.c_int, [_vp, _vp]),
+    "rails_ctx_rccl_size": (C.c_int, [_vp]),
+    "rails_csr_set_halo_counts": (C.c_int, [_vp, C.c_int, _i64p, _i64p]),
     "rails_csr_create": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, _i32p, _dp, C.POINTER(_vp)]),
     "rails_csr_create_callback": (C.c_int, [_vp, C.c_int64, APPLY_FN, _vp, C.POINTER(_vp)]),
     "rails_csr_destroy": (C.c_int, [_vp]),

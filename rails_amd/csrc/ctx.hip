@@ -60,6 +60,7 @@ extern "C" int rails_ctx_destroy(rails_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     rails_lanczos_release(c);
+    rails_rccl_release(c);
     for (auto &fp : c->free_panels) hipFree(fp.second);
     c->free_panels.clear();
     if (c->ws) hipFree(c->ws);
@@ -132,9 +133,13 @@ extern "C" int rails_ctx_set_allreduce(rails_ctx *c, rails_allreduce_fn fn, void
 int rails_allreduce_dev(rails_ctx *c, double *dev, size_t n)
 {
     if (n == 0) return RAILS_OK;
-    if (c->nranks <= 1 && !c->allreduce) return RAILS_OK; // a hook installed on a single rank is still honoured
+    if (c->nranks <= 1 && !c->allreduce && !c->rccl) return RAILS_OK; // a hook or communicator on a single rank is still honoured
+    if (!c->allreduce && c->rccl) { // native: RCCL on the context's stream
+        c->n_allreduce++;
+        return rails_rccl_allreduce(c, dev, n);
+    }
     if (!c->allreduce) {
-        rails_set_error("row-partitioned run (nranks=%d) without an all-reduce hook", c->nranks);
+        rails_set_error("row-partitioned run (nranks=%d) with neither an RCCL communicator (rails_ctx_init_rccl) nor an all-reduce hook", c->nranks);
         return RAILS_ECOMM;
     }
     c->n_allreduce++;

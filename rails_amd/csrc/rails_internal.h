@@ -55,6 +55,10 @@ struct rails_ctx {
     int64_t row0 = 0, m_global = -1;
     rails_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
+    // RCCL communicator over the ranks of the partition (rccl_comm.hip); used when no hook is installed
+    void *rccl = nullptr;
+    bool own_rccl = false;
+    int rccl_nranks = 0, rccl_rank = 0;
     // device workspace for reduction partials / small matrices
     double *ws = nullptr;
     size_t ws_bytes = 0;
@@ -110,6 +114,7 @@ struct rails_csr {
     size_t send_cap = 0, ext_cap = 0;
     rails_halo_fn halo = nullptr;
     void *halo_user = nullptr;
+    std::vector<int64_t> send_counts, recv_counts; // rows per neighbour rank (rails_csr_set_halo_counts): the RCCL form of the exchange
     // LDS-staged footprint kernel (spmm.hip): per row-block column footprints
     int variant = 0;
     bool tiled_ready = false;
@@ -178,6 +183,11 @@ int rails_pinned_reserve(rails_ctx *ctx, size_t bytes);
 int rails_pinned_begin_write(rails_ctx *ctx, size_t bytes);
 int rails_pinned_end_write(rails_ctx *ctx);
 int rails_allreduce_dev(rails_ctx *ctx, double *dev, size_t n);
+
+// rccl_comm.hip
+int rails_rccl_allreduce(rails_ctx *c, double *dev, size_t n);
+int rails_rccl_halo(rails_ctx *c, const rails_csr *A, const double *send_buf, double *recv_buf, int ncols);
+void rails_rccl_release(rails_ctx *c);
 
 // ---- kernels / launchers across translation units ----
 // spmm_sweep.hip: the sweep kernel for banded patterns; *done tells whether it computed the product

@@ -404,6 +404,22 @@ extern "C" int rails_csr_set_variant(rails_csr *A, int variant)
     return RAILS_OK;
 }
 
+extern "C" int rails_csr_set_halo_counts(rails_csr *A, int nranks, const int64_t *send_counts, const int64_t *recv_counts)
+{
+    RAILS_REQUIRE(A && nranks >= 1 && send_counts && recv_counts, "rails_csr_set_halo_counts: bad argument");
+    int64_t ns = 0, nr = 0;
+    for (int r = 0; r < nranks; ++r) {
+        RAILS_REQUIRE(send_counts[r] >= 0 && recv_counts[r] >= 0, "rails_csr_set_halo_counts: negative count");
+        ns += send_counts[r];
+        nr += recv_counts[r];
+    }
+    RAILS_REQUIRE(ns == A->n_send && nr == A->n_ghost, "rails_csr_set_halo_counts: counts add up to %lld sent / %lld received rows, the plan has %lld / %lld",
+                  (long long)ns, (long long)nr, (long long)A->n_send, (long long)A->n_ghost);
+    A->send_counts.assign(send_counts, send_counts + nranks);
+    A->recv_counts.assign(recv_counts, recv_counts + nranks);
+    return RAILS_OK;
+}
+
 extern "C" int rails_csr_set_halo(rails_csr *A, int64_t n_send, const int64_t *send_rows, int64_t n_ghost, rails_halo_fn fn,
                                   void *user)
 {
@@ -411,7 +427,8 @@ extern "C" int rails_csr_set_halo(rails_csr *A, int64_t n_send, const int64_t *s
     RAILS_REQUIRE(n_send >= 0 && n_ghost >= 0 && A->m + n_ghost == A->ncols_ext,
                   "rails_csr_set_halo: m_local %lld + ghosts %lld != extended columns %lld", (long long)A->m, (long long)n_ghost,
                   (long long)A->ncols_ext);
-    RAILS_REQUIRE((n_send == 0 && n_ghost == 0) || fn, "rails_csr_set_halo: halo hook missing");
+    RAILS_REQUIRE((n_send == 0 && n_ghost == 0) || fn || A->ctx->rccl,
+                  "rails_csr_set_halo: neither a halo hook nor an RCCL communicator on the context (rails_ctx_init_rccl)");
     for (int64_t i = 0; i < n_send; ++i)
         RAILS_REQUIRE(send_rows[i] >= 0 && send_rows[i] < A->m, "rails_csr_set_halo: send row %lld out of range", (long long)send_rows[i]);
     rails_ctx *c = A->ctx;
@@ -487,10 +504,15 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
             int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)c->num_cu * 8);
             hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, c->stream, A->send_rows, A->n_send, Xp, X->ld, nc, A->send_buf);
         }
-        int rc = A->halo(A->halo_user, A->send_buf, A->ext, nc, (void *)c->stream);
-        if (rc != 0) {
-            rails_set_error("rails_spmm: halo hook failed with code %d", rc);
-            return RAILS_ECOMM;
+        if (A->halo) {
+            int rc = A->halo(A->halo_user, A->send_buf, A->ext, nc, (void *)c->stream);
+            if (rc != 0) {
+                rails_set_error("rails_spmm: halo hook failed with code %d", rc);
+                return RAILS_ECOMM;
+            }
+        } else {
+            RAILS_REQUIRE(c->rccl, "rails_spmm: ghost rows but neither a halo hook nor an RCCL communicator");
+            RAILS_TRY(rails_rccl_halo(c, A, A->send_buf, A->ext, nc));
         }
         Xg = A->ext;
         ldg = nc;

@@ -61,6 +61,23 @@ class Context:
         self._cb = _lib.ALLREDUCE_FN(tramp)
         check(self.lib.rails_ctx_set_allreduce(self.h, self._cb, None), "rails_ctx_set_allreduce")
 
+    @staticmethod
+    def rccl_unique_id():
+        """128 bytes made by ONE rank and handed to every rank of the partition (any transport) for init_rccl."""
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        check(lib.rails_rccl_unique_id(buf), "rails_rccl_unique_id")
+        return buf.raw
+
+    def init_rccl(self, unique_id, nranks, rank):
+        """The library's own RCCL communicator (collective: every rank calls it): all-reduces and ghost-row exchanges then run
+        inside the library on the context's stream, no hook needed."""
+        assert len(unique_id) == 128
+        check(self.lib.rails_ctx_init_rccl(self.h, C.c_char_p(unique_id), nranks, rank), "rails_ctx_init_rccl")
+
+    def rccl_size(self):
+        return self.lib.rails_ctx_rccl_size(self.h)
+
     def sync(self):
         check(self.lib.rails_ctx_sync(self.h), "rails_ctx_sync")
 
@@ -364,10 +381,14 @@ class HipOperatorWrapper:
                 import traceback
                 traceback.print_exc()
                 return 1
-        self._halo_cb = _lib.HALO_FN(tramp)
+        self._halo_cb = _lib.HALO_FN(tramp) if pyfunc is not None else _lib.HALO_FN(0)  # None: the library's RCCL exchange
         rows = np.ascontiguousarray(plan.send_rows, dtype=np.int64)
         check(self.ctx.lib.rails_csr_set_halo(self.h.h, plan.n_send, rows.ctypes.data_as(C.POINTER(C.c_int64)), plan.n_ghost,
                                               self._halo_cb, None), "rails_csr_set_halo")
+        sc = np.ascontiguousarray(plan.send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(plan.recv_counts, dtype=np.int64)
+        check(self.ctx.lib.rails_csr_set_halo_counts(self.h.h, plan.nranks, sc.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     rc.ctypes.data_as(C.POINTER(C.c_int64))), "rails_csr_set_halo_counts")
 
     def apply(self, X, Y=None):
         """Y = op(A) * X (src/LyapunovSolver.hpp:146)."""
