@@ -39,16 +39,26 @@ extern "C" int rails_ctx_create(int device, void *stream, rails_ctx **out)
     rails_ctx *c = new rails_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
+    hipError_t he = hipSuccess;
     if (stream) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
     } else {
-        RAILS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
+        he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        c->own_stream = he == hipSuccess;
     }
-    RAILS_HIP_CHECK(hipEventCreate(&c->ev0));
-    RAILS_HIP_CHECK(hipEventCreate(&c->ev1));
-    RAILS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
+    if (he == hipSuccess) he = hipEventCreate(&c->ev0);
+    if (he == hipSuccess) he = hipEventCreate(&c->ev1);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming);
+    if (he != hipSuccess) { // nothing of a half-made context is left behind
+        rails_set_error("rails_ctx_create: stream / event creation failed: %s", hipGetErrorString(he));
+        if (c->ev0) hipEventDestroy(c->ev0);
+        if (c->ev1) hipEventDestroy(c->ev1);
+        if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
+        if (c->own_stream) hipStreamDestroy(c->stream);
+        delete c;
+        return RAILS_EHIP;
+    }
     rails_host_lapack_init(nullptr); // load the host LAPACK now (not inside the first solve); its absence is reported by the calls that need it
     *out = c;
     return RAILS_OK;
@@ -226,6 +236,7 @@ extern "C" int rails_timer_stop(rails_ctx *c, double *ms)
 
 extern "C" int rails_panel_create(rails_ctx *c, int64_t m_local, int capacity, rails_panel **out)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_REQUIRE(c && out, "rails_panel_create: null argument");
     RAILS_REQUIRE(m_local >= 0 && capacity >= 0, "rails_panel_create: bad shape %lld x %d", (long long)m_local, capacity);
     rails_panel *P = new rails_panel();
@@ -308,6 +319,7 @@ static inline int grid_for(rails_ctx *c, int64_t total, int block)
 
 extern "C" int rails_panel_reserve(rails_ctx *c, rails_panel *P, int capacity)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_REQUIRE(c && P, "null argument");
     if (capacity <= P->cap) return RAILS_OK;
     int nld = rails_pad_ld(capacity);
@@ -386,6 +398,7 @@ __global__ void k_gather_panel_to_cm(const double *__restrict__ P, int ld, doubl
 
 extern "C" int rails_panel_upload(rails_ctx *c, rails_panel *P, int c0, int nc, const double *host, int64_t ldh)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_TRY(check_window(P, c0, nc, "rails_panel_upload"));
     RAILS_REQUIRE(host || nc == 0 || P->m == 0, "rails_panel_upload: null host buffer");
     RAILS_REQUIRE(ldh >= P->m, "rails_panel_upload: ldh %lld < rows %lld", (long long)ldh, (long long)P->m);
@@ -406,6 +419,7 @@ extern "C" int rails_panel_upload(rails_ctx *c, rails_panel *P, int c0, int nc, 
 
 extern "C" int rails_panel_download(rails_ctx *c, const rails_panel *P, int c0, int nc, double *host, int64_t ldh)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_TRY(check_window(P, c0, nc, "rails_panel_download"));
     RAILS_REQUIRE(host || nc == 0 || P->m == 0, "rails_panel_download: null host buffer");
     RAILS_REQUIRE(ldh >= P->m, "rails_panel_download: ldh %lld < rows %lld", (long long)ldh, (long long)P->m);
@@ -480,6 +494,7 @@ __global__ void k_random(double *__restrict__ P, int ld, int64_t m, int nc, uint
 
 extern "C" int rails_panel_fill(rails_ctx *c, rails_panel *P, int c0, int nc, double value)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_TRY(check_window(P, c0, nc, "rails_panel_fill"));
     if (nc == 0 || P->m == 0) return RAILS_OK;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(c, P->m * nc, 256)), dim3(256), 0, c->stream, P->d + c0, P->ld, P->m, nc, value);
@@ -526,6 +541,7 @@ extern "C" int rails_panel_axpy(rails_ctx *c, double alpha, const rails_panel *X
 
 extern "C" int rails_panel_random(rails_ctx *c, rails_panel *P, int c0, int nc)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_TRY(check_window(P, c0, nc, "rails_panel_random"));
     uint64_t s = c->next_stream++;
     if (nc == 0 || P->m == 0) return RAILS_OK;

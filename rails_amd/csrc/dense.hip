@@ -373,6 +373,7 @@ int rails_gram_dev(rails_ctx *c, const double *X, int ldx, const double *Y, int 
 extern "C" int rails_gram(rails_ctx *c, const rails_panel *X, int xc0, int a, const rails_panel *Y, int yc0, int b, double *C_host,
                           int ldc)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     rails_slow_guard slow__(c, "rails_gram", a, b);
     RAILS_REQUIRE(c && X && Y, "rails_gram: null argument");
     RAILS_REQUIRE(a >= 0 && b >= 0 && xc0 >= 0 && yc0 >= 0 && xc0 + a <= X->cap && yc0 + b <= Y->cap,
@@ -421,6 +422,7 @@ int rails_panel_gemm_dev(rails_ctx *c, double alpha, const double *X, int ldx, i
 extern "C" int rails_panel_gemm_wide(rails_ctx *c, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc, int r,
                                      double beta, rails_panel *Y, int yc0)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     rails_slow_guard slow__(c, "rails_panel_gemm_wide", k, r);
     RAILS_REQUIRE(c && X && Y, "rails_panel_gemm_wide: null argument");
     RAILS_REQUIRE(k >= 0 && r >= 0 && xc0 >= 0 && yc0 >= 0 && xc0 + k <= X->cap && yc0 + r <= Y->cap,
@@ -450,6 +452,7 @@ extern "C" int rails_panel_gemm_wide(rails_ctx *c, double alpha, const rails_pan
 extern "C" int rails_panel_gemm(rails_ctx *c, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc,
                                 int r, double beta, rails_panel *Y, int yc0)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     rails_slow_guard slow__(c, "rails_panel_gemm", k, r);
     RAILS_REQUIRE(c && X && Y, "rails_panel_gemm: null argument");
     RAILS_REQUIRE(k >= 0 && r >= 0 && xc0 >= 0 && yc0 >= 0 && xc0 + k <= X->cap && yc0 + r <= Y->cap,

@@ -592,18 +592,21 @@ extern "C" int rails_resid_lanczos(rails_ctx *c, const rails_panel *AV, int avc0
                                    const double *T_host, int ldt, const rails_panel *B, int bc0, int p, int L, double *H_host,
                                    int ldh, int *steps_out)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     return lz_run(c, AV, avc0, MV, mvc0, k, T_host, ldt, B, bc0, p, L, H_host, ldh, steps_out, nullptr);
 }
 
 extern "C" int rails_lanczos_start(rails_ctx *c, const rails_panel *AV, int avc0, const rails_panel *MV, int mvc0, int k,
                                    const rails_panel *B, int bc0, int p, double *sums_host)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_REQUIRE(sums_host, "rails_lanczos_start: null output");
     return lz_run(c, AV, avc0, MV, mvc0, k, nullptr, 0, B, bc0, p, 1, nullptr, 0, nullptr, sums_host);
 }
 
 extern "C" int rails_lanczos_vectors(rails_ctx *c, const double *S_host, int lds, int w, rails_panel *Out, int oc0)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_REQUIRE(c && Out, "rails_lanczos_vectors: null argument");
     rails_lanczos_state &S = lz_state(c);
     RAILS_REQUIRE(S.Qc && S.steps > 0, "rails_lanczos_vectors: no Lanczos run to take vectors from");

@@ -161,6 +161,7 @@ int repair_block(rails_ctx *c, rails_panel *V, int k_old, int w, const std::vect
 
 extern "C" int rails_orthogonalize(rails_ctx *c, rails_panel *V, int k_old, int w, int method, int *used)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_REQUIRE(c && V, "rails_orthogonalize: null argument");
     RAILS_REQUIRE(k_old >= 0 && w >= 0 && k_old + w <= V->cap, "rails_orthogonalize: columns [%d,%d) outside capacity %d", k_old,
                   k_old + w, V->cap);

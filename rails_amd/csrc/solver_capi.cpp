@@ -6,6 +6,9 @@
 #include <string>
 #include <vector>
 
+#include <exception>
+#include <new>
+
 #include "rails/HipSolverOps.hpp"
 #include "rails/SubspaceSolverOps.hpp"
 #include "rails_solver.h"
@@ -59,7 +62,7 @@ struct rails_solver {
 
 extern "C" int rails_solver_create(rails_ctx *ctx, rails_csr *A, rails_csr *M, const double *B_host, int64_t ldb, int p, int64_t m_global,
                                    rails_solver **out)
-{
+try {
     if (!ctx || !A || !out || (p > 0 && !B_host) || p < 0) {
         rails_set_error("rails_solver_create: bad argument");
         return RAILS_EINVAL;
@@ -88,6 +91,12 @@ extern "C" int rails_solver_create(rails_ctx *ctx, rails_csr *A, rails_csr *M, c
     s->V.set_global_rows(s->m_global);
     *out = s;
     return RAILS_OK;
+} catch (std::bad_alloc const &) {
+    rails_set_error("rails_solver_create: out of host memory");
+    return RAILS_ENOMEM;
+} catch (std::exception const &e) {
+    rails_set_error("rails_solver_create: %s", e.what());
+    return RAILS_EINVAL;
 }
 
 extern "C" int rails_solver_destroy(rails_solver *s)
@@ -220,11 +229,19 @@ extern "C" int rails_solver_solve(rails_solver *s, int *code, int *k)
     s->last_was_subspace = s->subspace && (s->have_V0 || !restart_from_solution);
     rails::clear_sticky_error();
     int rc;
-    if (s->last_was_subspace) {
-        rc = solve_in_coordinates(s);
-        if (rc == -1000) return RAILS_EHIP;
-    } else
-        rc = s->solver->solve(s->V, s->T);
+    try { // the solver templates allocate (std::vector, make_shared): nothing may unwind through the C boundary
+        if (s->last_was_subspace) {
+            rc = solve_in_coordinates(s);
+            if (rc == -1000) return RAILS_EHIP;
+        } else
+            rc = s->solver->solve(s->V, s->T);
+    } catch (std::bad_alloc const &) {
+        rails_set_error("rails_solver_solve: out of host memory");
+        return RAILS_ENOMEM;
+    } catch (std::exception const &e) {
+        rails_set_error("rails_solver_solve: %s", e.what());
+        return RAILS_EINVAL;
+    }
     s->have_V0 = false; // V now holds the result; a later warm start passes its V again (or runs on the direct back end)
     if (code) *code = rc;
     if (k) *k = s->V.N();

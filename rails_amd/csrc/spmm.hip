@@ -295,6 +295,7 @@ int build_transpose(rails_csr *A)
 extern "C" int rails_csr_create(rails_ctx *c, int64_t m_local, int64_t n_cols_ext, const int64_t *rowptr, const int32_t *col,
                                 const double *val, rails_csr **out)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_REQUIRE(c && out && rowptr, "rails_csr_create: null argument");
     RAILS_REQUIRE(m_local >= 0 && n_cols_ext >= 0 && n_cols_ext <= 0x7fffffffLL, "rails_csr_create: bad shape %lld x %lld",
                   (long long)m_local, (long long)n_cols_ext);
@@ -344,12 +345,15 @@ extern "C" int rails_csr_create(rails_ctx *c, int64_t m_local, int64_t n_cols_ex
         rails_csr_destroy(A);
         return RAILS_ENOMEM;
     }
-    RAILS_HIP_CHECK(hipMemcpyAsync(A->rowptr, rowptr, (size_t)(m_local + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-    if (nnz) {
-        RAILS_HIP_CHECK(hipMemcpyAsync(A->col, col, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        RAILS_HIP_CHECK(hipMemcpyAsync(A->val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipError_t ce = hipMemcpyAsync(A->rowptr, rowptr, (size_t)(m_local + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    if (ce == hipSuccess && nnz) ce = hipMemcpyAsync(A->col, col, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    if (ce == hipSuccess && nnz) ce = hipMemcpyAsync(A->val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
+    if (ce != hipSuccess) { // the half-made operator is released, not leaked
+        rails_set_error("rails_csr_create: upload failed: %s", hipGetErrorString(ce));
+        rails_csr_destroy(A);
+        return RAILS_EHIP;
     }
-    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
     *out = A;
     return RAILS_OK;
 }
@@ -453,6 +457,7 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
 
 extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_panel *X, int xc0, int nc, rails_panel *Y, int yc0)
 {
+    if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     rails_slow_guard slow__(c, "rails_spmm", nc, A ? A->m : 0);
     RAILS_REQUIRE(c && A && X && Y, "rails_spmm: null argument");
     RAILS_REQUIRE(xc0 >= 0 && nc >= 0 && xc0 + nc <= X->cap, "rails_spmm: X columns [%d,%d) outside capacity %d", xc0, xc0 + nc, X->cap);

@@ -36,6 +36,7 @@ constexpr int RING_BYTES = SEG * NSEG * 128;
 struct SweepArgs {
     int64_t ldx, ldg, ldy, m, ncols;
     int parts, n_chunks, phases;
+    int stagger; // 0..3: waves W/2.. start every step 0 / 128 / 256 / 512 cycles late (RAILS_SWEEP_STAGGER)
     int ablate; // experiments only (RAILS_SWEEP_ABLATE): 1 = no LDS-DMA after the first step, 2 = no trips, 4 = no barriers; 16 / 32 / 48 = the
                 // builds without ring-row reads / multiply-adds / stream waits (results are wrong in every case)
 };
@@ -200,6 +201,7 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
         prm.nseg = NSEG;
         prm.parts = 8;
         prm.phases = 32 / n_chunks;
+        if (getenv("RAILS_SWEEP_LEVEL")) prm.level = atoi(getenv("RAILS_SWEEP_LEVEL")); // experiments: 0 = no levelling of the units over the steps
         if (rails_sweep_plan_build(prm, A->m, A->ncols_ext, A->h_rowptr.data(), A->h_col.data(), A->h_val.data(), d->host)) {
             RAILS_TRY(up(c, &d->part_row0, d->host.part_row0));
             RAILS_TRY(up(c, &d->sweep0, d->host.sweep0));
@@ -235,6 +237,8 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
     a.phases = 32 / n_chunks;
     static const int ablate = getenv("RAILS_SWEEP_ABLATE") ? atoi(getenv("RAILS_SWEEP_ABLATE")) : 0;
     a.ablate = ablate;
+    static const int stagger = getenv("RAILS_SWEEP_STAGGER") ? atoi(getenv("RAILS_SWEEP_STAGGER")) : 0;
+    a.stagger = stagger;
 #define RAILS_SWEEP_LAUNCH(K)                                                                                                                     \
     hipLaunchKernelGGL((K<SWEEP_W, SWEEP_G>), dim3(256), dim3(SWEEP_W * 64), 0, c->stream, a, d->part_row0, d->sweep0, d->nsteps, d->hdr_off, \
                        d->batch_off, d->flush_off, d->codes, d->vals, d->offs, d->flush_rows, X, Xg, Y)

@@ -4,17 +4,21 @@
 #include <algorithm>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
 
 constexpr int SLOTS = 8;
 
+// the schedule of one group: its units (four trips each, or a flush without trips) in execution order
 struct GroupSchedule {
-    std::vector<uint8_t> count;   // [nsteps] units of 4 trips | flush << 7
-    std::vector<double> val;      // [trips][8]
-    std::vector<uint16_t> off;    // [trips][8]
-    std::vector<int32_t> flush;   // first row of the wave's slot octet, per flush, in step order
+    std::vector<int> step;        // per unit: the step it runs in
+    std::vector<int> earliest;    // per unit: the first step at which all its X rows are in the ring
+    std::vector<uint8_t> flags;   // per unit: 1 = the group's partial sums go to Y afterwards, 2 = no trips
+    std::vector<double> val;      // [units with trips][4][8]
+    std::vector<uint16_t> off;
+    std::vector<int32_t> flush;   // first row of the wave's slot octet, per flush, in order
 };
 
 struct Ctx {
@@ -35,7 +39,9 @@ bool schedule_group(const Ctx &c, int phase, int wave, int g, GroupSchedule &out
     const rails_sweep_params &P = *c.prm;
     const int SEG = P.seg_rows, NSEG = P.nseg;
     const int ring = SEG * NSEG;
-    out.count.assign(c.nsteps, 0);
+    out.step.clear();
+    out.earliest.clear();
+    out.flags.clear();
     out.val.clear();
     out.off.clear();
     out.flush.clear();
@@ -121,44 +127,55 @@ bool schedule_group(const Ctx &c, int phase, int wave, int g, GroupSchedule &out
             why = "more than 508 nonzeros of one row inside one ring of X rows";
             return false;
         }
-        for (int t = 0; t < T; ++t) {
-            double v[SLOTS];
-            int64_t o[SLOTS];
-            int first_real = -1;
-            for (int s = 0; s < SLOTS; ++s) {
-                v[s] = 0.0;
-                o[s] = -1;
-                if (p[s] < pe[s]) {
-                    const int64_t pos = (int64_t)c.col[p[s]] - c.sweep0;
-                    if (pos < hi) {
-                        v[s] = c.val[p[s]];
-                        o[s] = pos;
-                        last_pos[s] = pos;
-                        ++p[s];
-                        if (first_real < 0) first_real = s;
+        for (int u = 0; u < units; ++u) {
+            double v[4][SLOTS];
+            int64_t o[4][SLOTS];
+            int64_t first_real = -1, newest = -1;
+            for (int t = 0; t < 4; ++t)
+                for (int s = 0; s < SLOTS; ++s) {
+                    v[t][s] = 0.0;
+                    o[t][s] = -1;
+                    if (p[s] < pe[s]) {
+                        const int64_t pos = (int64_t)c.col[p[s]] - c.sweep0;
+                        if (pos < hi) {
+                            v[t][s] = c.val[p[s]];
+                            o[t][s] = pos;
+                            ++p[s];
+                            if (first_real < 0) first_real = pos;
+                            newest = std::max(newest, pos);
+                        }
                     }
                 }
-            }
-            for (int s = 0; s < SLOTS; ++s) {
-                // an idle slot multiplies an X row by zero: its own last one while that is still in the ring, else a neighbour's
-                // (a trip that only rounds a unit up to four has no neighbour: the newest row of the ring)
-                if (o[s] < 0) o[s] = (last_pos[s] >= 0 && last_pos[s] >= lo) ? last_pos[s] : (first_real >= 0 ? o[first_real] : hi - 1);
-                out.val.push_back(v[s]);
-                out.off.push_back((uint16_t)(o[s] % ring));
-            }
+            // an idle slot multiplies an X row by zero: the row of its own previous nonzero while that is still in the ring, else
+            // the first row this unit reads anyway (both are there at whatever step the unit ends up running)
+            for (int t = 0; t < 4; ++t)
+                for (int s = 0; s < SLOTS; ++s) {
+                    if (o[t][s] >= 0)
+                        last_pos[s] = o[t][s];
+                    else
+                        o[t][s] = (last_pos[s] >= 0 && last_pos[s] >= lo) ? last_pos[s] : first_real;
+                    out.val.push_back(v[t][s]);
+                    out.off.push_back((uint16_t)(o[t][s] % ring));
+                }
+            out.step.push_back(k);
+            out.earliest.push_back((int)(newest / SEG));
+            out.flags.push_back(0);
         }
         bool done = true;
         for (int s = 0; s < SLOTS; ++s) done = done && p[s] == pe[s];
-        uint8_t code = (uint8_t)units;
         if (done) {
             if (any_valid) {
-                code |= 0x80;
+                if (units == 0) { // rows without (remaining) nonzeros: a flush of its own, tied to this step
+                    out.step.push_back(k);
+                    out.earliest.push_back(k);
+                    out.flags.push_back(2);
+                }
+                out.flags.back() |= 1;
                 out.flush.push_back((int32_t)cur_row0);
             }
             loaded = false;
             bj += P.phases;
         }
-        out.count[k] = code;
     }
     if (loaded || bj < c.nblocks) {
         // blocks left over after the last step: only possible for rows without nonzeros beyond the swept range
@@ -200,7 +217,7 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                 return false;
             }
     int64_t staged = 0;
-    std::vector<GroupSchedule> gs(G);
+    std::vector<std::vector<GroupSchedule>> all(W, std::vector<GroupSchedule>(G));
     for (int x = 0; x < prm.parts; ++x) {
         Ctx c;
         c.prm = &prm;
@@ -226,11 +243,53 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
         plan.sweep0[x] = c.sweep0;
         plan.nsteps[x] = c.nsteps;
         staged += (int64_t)c.nsteps * SEG * P;
-        for (int ph = 0; ph < P; ++ph)
+        for (int ph = 0; ph < P; ++ph) {
+            for (int w = 0; w < W; ++w)
+                for (int g = 0; g < G; ++g)
+                    if (!schedule_group(c, ph, w, g, all[w][g], plan.why)) return false;
+            // Level the work of the workgroup's waves step by step: all of them meet at a barrier every step, so a step costs what
+            // its busiest wave costs (unlevelled: the sum over the steps of the busiest wave's units is 1.32 x the mean wave's).  The
+            // schedule above runs a unit as late as its X rows allow; it may run earlier, down to the step in which the last of its
+            // rows arrives, as long as the units of its group stay in order.  From the last step backwards, a wave above the step's
+            // mean over the waves hands the first unit of a group to the step before.
+            if (prm.level) {
+                std::vector<std::vector<int>> load(W, std::vector<int>(c.nsteps, 0));
+                for (int w = 0; w < W; ++w)
+                    for (int g = 0; g < G; ++g)
+                        for (size_t u = 0; u < all[w][g].step.size(); ++u)
+                            if (!(all[w][g].flags[u] & 2)) ++load[w][all[w][g].step[u]];
+                std::vector<size_t> head(G);
+                for (int k = c.nsteps - 1; k >= 1; --k) {
+                    int sum = 0;
+                    for (int w = 0; w < W; ++w) sum += load[w][k];
+                    const int target = (sum + W - 1) / W;
+                    for (int w = 0; w < W; ++w) {
+                        if (load[w][k] <= target) continue;
+                        std::vector<GroupSchedule> &gs = all[w];
+                        for (int g = 0; g < G; ++g) {
+                            size_t u = 0;
+                            while (u < gs[g].step.size() && gs[g].step[u] < k) ++u;
+                            head[g] = u;
+                        }
+                        bool moved = true;
+                        while (load[w][k] > target && moved) {
+                            moved = false;
+                            for (int g = 0; g < G && load[w][k] > target; ++g) {
+                                const size_t u = head[g];
+                                if (u >= gs[g].step.size() || gs[g].step[u] != k || (gs[g].flags[u] & 2) || gs[g].earliest[u] > k - 1) continue;
+                                gs[g].step[u] = k - 1;
+                                ++head[g];
+                                --load[w][k];
+                                ++load[w][k - 1];
+                                moved = true;
+                            }
+                        }
+                    }
+                }
+            }
             for (int w = 0; w < W; ++w) {
                 const int64_t prog = ((int64_t)x * P + ph) * W + w;
-                for (int g = 0; g < G; ++g)
-                    if (!schedule_group(c, ph, w, g, gs[g], plan.why)) return false;
+                std::vector<GroupSchedule> &gs = all[w];
                 // serialise: per step a record of RAILS_SWEEP_CODES 16-bit entries: [0] = n, then one entry per unit of four trips (or per
                 // flush without trips): group | flush after << 6 | no trips << 7, in group order; the trips in the same order, 16
                 // trips per batch: lane q of a slot holds trips q and q + 8 of the batch
@@ -239,41 +298,42 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                 uint16_t *h = plan.codes.data() + plan.hdr_off[prog];
                 plan.batch_off[prog] = (int64_t)(plan.vals.size() / 128);
                 plan.flush_off[prog] = (int64_t)plan.flush_rows.size();
-                std::vector<size_t> tp(G, 0), fp(G, 0); // per group: next trip / next flush
-                int64_t trip = 0;                       // trips of this wave so far
+                std::vector<size_t> up(G, 0), tp(G, 0), fp(G, 0); // per group: next unit / next unit with trips / next flush
+                int64_t trip = 0;                                  // trips of this wave so far
                 for (int k = 0; k < c.nsteps; ++k) {
                     int n = 0;
                     uint16_t *rec = h + (size_t)k * RAILS_SWEEP_CODES;
-                    for (int g = 0; g < G; ++g) {
-                        const uint8_t code = gs[g].count[k];
-                        if (!code) continue;
-                        const int units = code & 0x7f;
-                        const bool flush = (code & 0x80) != 0;
-                        if (n + std::max(units, 1) > RAILS_SWEEP_CODES - 1) {
-                            plan.why = "more than 127 units of one wave in one step (step " + std::to_string(k) + " of " + std::to_string(c.nsteps) + ", part " + std::to_string(x) + ")";
-                            return false;
-                        }
-                        if (units == 0) rec[1 + n++] = (uint16_t)(g | 0x40 | 0x80);
-                        for (int u = 0; u < units; ++u) rec[1 + n++] = (uint16_t)(g | ((flush && u == units - 1) ? 0x40 : 0));
-                        for (int t = 0; t < 4 * units; ++t, ++trip) {
-                            const int64_t b = plan.batch_off[prog] + trip / 16;
-                            if ((size_t)(b + 1) * 128 > plan.vals.size()) {
-                                plan.vals.resize((size_t)(b + 1) * 128, 0.0);
-                                plan.offs.resize((size_t)(b + 1) * 128, 0);
+                    for (int g = 0; g < G; ++g)
+                        while (up[g] < gs[g].step.size() && gs[g].step[up[g]] == k) {
+                            const uint8_t fl = gs[g].flags[up[g]++];
+                            if (n + 1 > RAILS_SWEEP_CODES - 1) {
+                                plan.why = "more than 127 units of one wave in one step (step " + std::to_string(k) + " of " + std::to_string(c.nsteps) + ", part " + std::to_string(x) + ")";
+                                return false;
                             }
-                            for (int s = 0; s < SLOTS; ++s) {
-                                const size_t at = (size_t)b * 128 + (size_t)s * 16 + (size_t)(trip % 8) * 2 + (size_t)(trip % 16) / 8;
-                                plan.vals[at] = gs[g].val[tp[g] * 8 + s];
-                                plan.offs[at] = gs[g].off[tp[g] * 8 + s];
+                            rec[1 + n++] = (uint16_t)(g | ((fl & 1) ? 0x40 : 0) | ((fl & 2) ? 0x80 : 0));
+                            if (!(fl & 2)) {
+                                for (int t = 0; t < 4; ++t, ++trip) {
+                                    const int64_t b = plan.batch_off[prog] + trip / 16;
+                                    if ((size_t)(b + 1) * 128 > plan.vals.size()) {
+                                        plan.vals.resize((size_t)(b + 1) * 128, 0.0);
+                                        plan.offs.resize((size_t)(b + 1) * 128, 0);
+                                    }
+                                    for (int s = 0; s < SLOTS; ++s) {
+                                        const size_t at = (size_t)b * 128 + (size_t)s * 16 + (size_t)(trip % 8) * 2 + (size_t)(trip % 16) / 8;
+                                        plan.vals[at] = gs[g].val[(tp[g] * 4 + t) * 8 + s];
+                                        plan.offs[at] = gs[g].off[(tp[g] * 4 + t) * 8 + s];
+                                    }
+                                }
+                                ++tp[g];
                             }
-                            ++tp[g];
+                            if (fl & 1) plan.flush_rows.push_back(gs[g].flush[fp[g]++]);
                         }
-                        if (flush) plan.flush_rows.push_back(gs[g].flush[fp[g]++]);
-                    }
                     rec[0] = (uint16_t)n;
+                    plan.max_units_per_step = std::max(plan.max_units_per_step, n);
                 }
                 plan.trips += trip;
             }
+        }
     }
     // spare batches at the very end: the kernel requests batches up to six ahead of the trips it runs
     plan.vals.resize(plan.vals.size() + 8 * 128, 0.0);
@@ -304,6 +364,7 @@ extern "C" int rails_sweep_plan_create(int64_t m, int64_t ncols, const int64_t *
         prm.nseg = params[3];
         prm.parts = params[4];
         prm.phases = params[5];
+        if (getenv("RAILS_SWEEP_LEVEL")) prm.level = atoi(getenv("RAILS_SWEEP_LEVEL"));
     }
     rails_sweep_plan *pl = new rails_sweep_plan();
     if (!rails_sweep_plan_build(prm, m, ncols, rowptr, col, val, *pl)) {
@@ -334,6 +395,7 @@ extern "C" int rails_sweep_plan_info(const rails_sweep_plan *pl, int64_t *iinfo,
     iinfo[7] = pl->trips;
     iinfo[8] = pl->nnz;
     iinfo[9] = (int64_t)(pl->vals.size() / 128);
+    iinfo[10] = pl->max_units_per_step;
     dinfo[0] = pl->efficiency;
     dinfo[1] = pl->staged_rows_per_row;
     return RAILS_OK;

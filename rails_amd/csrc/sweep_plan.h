@@ -35,6 +35,7 @@ struct rails_sweep_params {
     int nseg = 5;       // ring segments (NSEG - 1 are readable while one is being filled)
     int parts = 8;      // row ranges (XCDs)
     int phases = 4;     // workgroups per (part, column chunk)
+    int level = 1;      // level every wave's units over the steps (0: run every unit as late as its X rows allow)
 };
 
 struct rails_sweep_plan {
@@ -53,6 +54,7 @@ struct rails_sweep_plan {
     std::vector<uint16_t> offs;              // same indexing: ring row of the X row to read
     std::vector<int32_t> flush_rows;         // first row (of the wave's 8 x G rows: + g * 64 * ... see kernel) per flush
     // statistics
+    int max_units_per_step = 0;              // the busiest (wave, step)
     int64_t trips = 0;                       // lock-step trips over all programs
     int64_t entries = 0;                     // = nnz when feasible
     double efficiency = 0.0;                 // nnz / (8 * trips)

@@ -78,6 +78,21 @@ def wrap_buffer(ptr, n, on_device):
     return torch.from_numpy(arr)
 
 
+def _on_stream(stream, on_device):
+    """torch.distributed orders its device work against torch's CURRENT stream: make that the stream the library passes (its own,
+    when the context was not created on a torch stream), so that the collective runs after the kernels that produced the buffer and
+    before the library's next use of it."""
+    import contextlib
+
+    if not on_device or not stream:
+        return contextlib.nullcontext()
+    import torch
+
+    if torch.cuda.current_stream().cuda_stream == stream:
+        return contextlib.nullcontext()
+    return torch.cuda.stream(torch.cuda.ExternalStream(stream))
+
+
 def make_allreduce(on_device=True, group=None, host_staged=False):
     """pyfunc(dev_ptr, n, stream) for Context.set_allreduce / the oracle's hook.  host_staged: device buffers travel through host
     tensors (rehearsals of the multi-process path on a backend without device collectives, i.e. gloo)."""
@@ -86,6 +101,10 @@ def make_allreduce(on_device=True, group=None, host_staged=False):
     wrapped = {}  # (ptr, n) -> tensor view: the library re-uses one small device buffer, wrapping it costs more than the collective
 
     def allreduce(ptr, n, stream):
+        with _on_stream(stream, on_device):
+            return _allreduce(ptr, n)
+
+    def _allreduce(ptr, n):
         t = wrapped.get((ptr, n))
         if t is None:
             if len(wrapped) > 64:
@@ -107,6 +126,10 @@ def make_halo(plan, on_device=True, group=None, host_staged=False):
     import torch.distributed as dist
 
     def halo(send_ptr, recv_ptr, ncols, stream):
+        with _on_stream(stream, on_device):
+            return _halo(send_ptr, recv_ptr, ncols)
+
+    def _halo(send_ptr, recv_ptr, ncols):
         send = wrap_buffer(send_ptr, plan.n_send * ncols, on_device)
         recv = wrap_buffer(recv_ptr, plan.n_ghost * ncols, on_device)
         dev_recv = None
