@@ -977,12 +977,13 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
 {
     const int W = (int)iinfo[0], G = (int)iinfo[1], SEG = (int)iinfo[2], NSEG = (int)iinfo[3], parts = (int)iinfo[4], P = (int)iinfo[5];
     const int CPS = (int)iinfo[6]; // entries per (program, step) record
+    const int SLOTS = (int)iinfo[11]; // rows of a group in one wave (16: a slot is a quad of lanes)
     std::vector<int> written((size_t)m * n_chunks, 0);
     int rc = 0;
 #pragma omp parallel for collapse(2) schedule(dynamic)
     for (int x = 0; x < parts; ++x)
         for (int q = 0; q < n_chunks; ++q) {
-            std::vector<double> acc((size_t)G * 8 * 16);
+            std::vector<double> acc((size_t)G * SLOTS * 16);
             for (int ph = 0; ph < P; ++ph)
                 for (int w = 0; w < W; ++w) {
                     const int64_t prog = ((int64_t)x * P + ph) * W + w;
@@ -1000,10 +1001,11 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
                             }
                             for (int t = 0; t < T; ++t, ++trip) {
                                 const int64_t b = batch_off[prog] + trip / 16;
-                                for (int s = 0; s < 8; ++s) {
-                                    const size_t at = (size_t)b * 128 + (size_t)s * 16 + (size_t)(trip % 8) * 2 + (size_t)(trip % 16) / 8;
-                                    const double v = vals[at];
-                                    const int o = offs[at];
+                                const int tt = (int)(trip % 16), unit = tt / 4, ql = tt % 4;
+                                for (int s = 0; s < SLOTS; ++s) {
+                                    const size_t lane = (size_t)s * 4 + ql;
+                                    const double v = vals[(size_t)b * 256 + (size_t)(unit / 2) * 128 + lane * 2 + (unit % 2)];
+                                    const int o = offs[(size_t)b * 256 + lane * 4 + unit];
                                     const int seg = o / SEG;
                                     const int back = ((k - seg) % NSEG + NSEG) % NSEG; // steps since that segment was filled
                                     const int kk = k - back;
@@ -1014,15 +1016,15 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
                                     }
                                     int64_t xrow = sweep0[x] + (int64_t)kk * SEG + o % SEG;
                                     xrow = xrow < 0 ? 0 : (xrow >= ncols ? ncols - 1 : xrow);
-                                    double *a = &acc[((size_t)g * 8 + s) * 16];
+                                    double *a = &acc[((size_t)g * SLOTS + s) * 16];
                                     for (int c = 0; c < 16; ++c) a[c] += v * X[xrow + (int64_t)(q * 16 + c) * ldx];
                                 }
                             }
                             if (code & 0x40) {
                                 const int64_t row0 = flush_rows[flush_off[prog] + fl++];
-                                for (int s = 0; s < 8; ++s) {
+                                for (int s = 0; s < SLOTS; ++s) {
                                     const int64_t row = row0 + s;
-                                    double *a = &acc[((size_t)g * 8 + s) * 16];
+                                    double *a = &acc[((size_t)g * SLOTS + s) * 16];
                                     if (row < part_row0[x + 1]) {
                                         for (int c = 0; c < 16; ++c) Y[row + (int64_t)(q * 16 + c) * ldy] = a[c];
 #pragma omp atomic

@@ -36,7 +36,7 @@ constexpr int RING_BYTES = SEG * NSEG * 128;
 struct SweepArgs {
     int64_t ldx, ldg, ldy, m, ncols;
     int parts, n_chunks, phases;
-    int stagger; // 0..3: waves W/2.. start every step 0 / 128 / 256 / 512 cycles late (RAILS_SWEEP_STAGGER)
+    int layout;  // experiments only (RAILS_SWEEP_LAYOUT): 1 = every lane reads 32 contiguous bytes of a ring row
     int ablate; // experiments only (RAILS_SWEEP_ABLATE): 1 = no LDS-DMA after the first step, 2 = no trips, 4 = no barriers; 16 / 32 / 48 = the
                 // builds without ring-row reads / multiply-adds / stream waits (results are wrong in every case)
 };
@@ -67,7 +67,6 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_IDX(TEXT) TEXT
 #define RAILS_SW_DPPSFX "_dpp"
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-#define RAILS_SW_SH(DPP) DPP
 #include "spmm_sweep_kernel.inc"
 // experiments: without the ring-row reads / the multiply-adds / the waits for the schedule stream
 #define RAILS_SW_NAME k_spmm_sweep_noread
@@ -77,7 +76,6 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_IDX(TEXT) TEXT
 #define RAILS_SW_DPPSFX "_dpp"
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-#define RAILS_SW_SH(DPP) DPP
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_nofma
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -86,7 +84,6 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_IDX(TEXT) TEXT
 #define RAILS_SW_DPPSFX "_dpp"
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-#define RAILS_SW_SH(DPP) DPP
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_nowait
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -95,7 +92,6 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_IDX(TEXT) TEXT
 #define RAILS_SW_DPPSFX "_dpp"
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-#define RAILS_SW_SH(DPP) DPP
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_noidx
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -104,7 +100,6 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_IDX(TEXT) ""
 #define RAILS_SW_DPPSFX "_dpp"
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-#define RAILS_SW_SH(DPP) DPP
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_bare
 #define RAILS_SW_READ(DST, ADDR) ""
@@ -113,7 +108,6 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_IDX(TEXT) TEXT
 #define RAILS_SW_DPPSFX "_dpp"
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-#define RAILS_SW_SH(DPP) DPP
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_nodpp
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -122,7 +116,6 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_IDX(TEXT) TEXT
 #define RAILS_SW_DPPSFX ""
 #define RAILS_SW_QP(T) ""
-#define RAILS_SW_SH(DPP) ""
 #include "spmm_sweep_kernel.inc"
 
 struct DevPlan {
@@ -176,7 +169,7 @@ void rails_sweep_release(rails_csr *A)
 }
 
 // the geometry the kernel is instantiated for
-static constexpr int SWEEP_W = 8, SWEEP_G = 44;
+static constexpr int SWEEP_W = 8, SWEEP_G = 22;
 
 // *done = true when the product was computed here.  force: fail instead of declining.
 int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool aligned,
@@ -237,8 +230,8 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
     a.phases = 32 / n_chunks;
     static const int ablate = getenv("RAILS_SWEEP_ABLATE") ? atoi(getenv("RAILS_SWEEP_ABLATE")) : 0;
     a.ablate = ablate;
-    static const int stagger = getenv("RAILS_SWEEP_STAGGER") ? atoi(getenv("RAILS_SWEEP_STAGGER")) : 0;
-    a.stagger = stagger;
+    static const int layout = getenv("RAILS_SWEEP_LAYOUT") ? atoi(getenv("RAILS_SWEEP_LAYOUT")) : 0;
+    a.layout = layout;
 #define RAILS_SWEEP_LAUNCH(K)                                                                                                                     \
     hipLaunchKernelGGL((K<SWEEP_W, SWEEP_G>), dim3(256), dim3(SWEEP_W * 64), 0, c->stream, a, d->part_row0, d->sweep0, d->nsteps, d->hdr_off, \
                        d->batch_off, d->flush_off, d->codes, d->vals, d->offs, d->flush_rows, X, Xg, Y)

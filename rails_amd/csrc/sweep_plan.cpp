@@ -9,14 +9,14 @@
 
 namespace {
 
-constexpr int SLOTS = 8;
+constexpr int SLOTS = 16; // rows of a group in one wave: a slot is a quad of lanes, each lane four of the row's 16 columns
 
 // the schedule of one group: its units (four trips each, or a flush without trips) in execution order
 struct GroupSchedule {
     std::vector<int> step;        // per unit: the step it runs in
     std::vector<int> earliest;    // per unit: the first step at which all its X rows are in the ring
     std::vector<uint8_t> flags;   // per unit: 1 = the group's partial sums go to Y afterwards, 2 = no trips
-    std::vector<double> val;      // [units with trips][4][8]
+    std::vector<double> val;      // [units with trips][4][SLOTS]
     std::vector<uint16_t> off;
     std::vector<int32_t> flush;   // first row of the wave's slot octet, per flush, in order
 };
@@ -296,7 +296,7 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                 plan.hdr_off[prog] = (int64_t)plan.codes.size();
                 plan.codes.resize(plan.codes.size() + (size_t)c.nsteps * RAILS_SWEEP_CODES, (uint16_t)0);
                 uint16_t *h = plan.codes.data() + plan.hdr_off[prog];
-                plan.batch_off[prog] = (int64_t)(plan.vals.size() / 128);
+                plan.batch_off[prog] = (int64_t)(plan.vals.size() / 256);
                 plan.flush_off[prog] = (int64_t)plan.flush_rows.size();
                 std::vector<size_t> up(G, 0), tp(G, 0), fp(G, 0); // per group: next unit / next unit with trips / next flush
                 int64_t trip = 0;                                  // trips of this wave so far
@@ -314,14 +314,18 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                             if (!(fl & 2)) {
                                 for (int t = 0; t < 4; ++t, ++trip) {
                                     const int64_t b = plan.batch_off[prog] + trip / 16;
-                                    if ((size_t)(b + 1) * 128 > plan.vals.size()) {
-                                        plan.vals.resize((size_t)(b + 1) * 128, 0.0);
-                                        plan.offs.resize((size_t)(b + 1) * 128, 0);
+                                    if ((size_t)(b + 1) * 256 > plan.vals.size()) {
+                                        plan.vals.resize((size_t)(b + 1) * 256, 0.0);
+                                        plan.offs.resize((size_t)(b + 1) * 256, 0);
                                     }
+                                    // trip tt of the batch = unit tt / 4, quad lane tt % 4: lane (slot, quad lane) holds four values, one per
+                                    // unit -- units 0, 1 in the first KiB of the batch, 2, 3 in the second (one 16-byte load each) -- and
+                                    // four 16-bit ring rows (one 8-byte load)
+                                    const int tt = (int)(trip % 16), unit = tt / 4, ql = tt % 4;
                                     for (int s = 0; s < SLOTS; ++s) {
-                                        const size_t at = (size_t)b * 128 + (size_t)s * 16 + (size_t)(trip % 8) * 2 + (size_t)(trip % 16) / 8;
-                                        plan.vals[at] = gs[g].val[(tp[g] * 4 + t) * 8 + s];
-                                        plan.offs[at] = gs[g].off[(tp[g] * 4 + t) * 8 + s];
+                                        const size_t lane = (size_t)s * 4 + ql;
+                                        plan.vals[(size_t)b * 256 + (size_t)(unit / 2) * 128 + lane * 2 + (unit % 2)] = gs[g].val[(tp[g] * 4 + t) * SLOTS + s];
+                                        plan.offs[(size_t)b * 256 + lane * 4 + unit] = gs[g].off[(tp[g] * 4 + t) * SLOTS + s];
                                     }
                                 }
                                 ++tp[g];
@@ -336,10 +340,10 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
         }
     }
     // spare batches at the very end: the kernel requests batches up to six ahead of the trips it runs
-    plan.vals.resize(plan.vals.size() + 8 * 128, 0.0);
-    plan.offs.resize(plan.offs.size() + 8 * 128, 0);
+    plan.vals.resize(plan.vals.size() + 8 * 256, 0.0);
+    plan.offs.resize(plan.offs.size() + 8 * 256, 0);
     plan.entries = plan.nnz;
-    plan.efficiency = plan.trips ? (double)plan.nnz / (8.0 * (double)plan.trips) : 1.0;
+    plan.efficiency = plan.trips ? (double)plan.nnz / ((double)SLOTS * (double)plan.trips) : 1.0;
     plan.staged_rows_per_row = m ? (double)staged / (double)m : 0.0;
     return true;
 }
@@ -394,7 +398,8 @@ extern "C" int rails_sweep_plan_info(const rails_sweep_plan *pl, int64_t *iinfo,
     iinfo[6] = RAILS_SWEEP_CODES;
     iinfo[7] = pl->trips;
     iinfo[8] = pl->nnz;
-    iinfo[9] = (int64_t)(pl->vals.size() / 128);
+    iinfo[9] = (int64_t)(pl->vals.size() / 256);
+    iinfo[11] = SLOTS;
     iinfo[10] = pl->max_units_per_step;
     dinfo[0] = pl->efficiency;
     dinfo[1] = pl->staged_rows_per_row;

@@ -11,9 +11,9 @@
 //            same X rows at the same time, so each X row is fetched from HBM once per part and served to the others
 //            by that XCD's L2
 //   chunks   column chunks of 16 (a 128-B line per X row); `phases` = workgroups per (part, chunk)
-//   blocks   a part's rows are cut into blocks of R = G * W * 8 rows; block j belongs to phase j % phases; a
-//            workgroup owns one block at a time: G groups x W waves x 8 slots, one row per slot, 16 partial sums
-//            per row spread over the slot's 8 lanes
+//   blocks   a part's rows are cut into blocks of R = G * W * 16 rows; block j belongs to phase j % phases; a
+//            workgroup owns one block at a time: G groups x W waves x 16 slots, one row per slot (a quad of lanes),
+//            16 partial sums per row, four per lane
 //   steps    sweep position s = column - sweep0(part); step k brings positions [k*SEG, (k+1)*SEG) into ring
 //            segment k % NSEG while the lanes may read positions [(k-NSEG+2)*SEG, (k+1)*SEG)
 //   trips    one trip = every slot of a wave consumes at most one nonzero of its row (lock step); trips come in units
@@ -30,7 +30,7 @@ constexpr int RAILS_SWEEP_CODES = 128; // 16-bit entries per (program, step) rec
 
 struct rails_sweep_params {
     int waves = 8;      // W: waves per workgroup
-    int groups = 44;    // G: row groups per wave (each: 8 slots = 8 rows)
+    int groups = 22;    // G: row groups per wave (each: 16 slots = 16 rows)
     int seg_rows = 256; // SEG: X rows per step
     int nseg = 5;       // ring segments (NSEG - 1 are readable while one is being filled)
     int parts = 8;      // row ranges (XCDs)
@@ -50,14 +50,15 @@ struct rails_sweep_plan {
     std::vector<int64_t> flush_off;          // [programs] offset into flush_rows
     std::vector<uint16_t> codes;             // per (program, step) RAILS_SWEEP_CODES entries: [0] = n, then n units of four trips:
                                              // group | flush after << 6 | no trips << 7, in group order
-    std::vector<double> vals;                // per batch of 16 trips: [slot 8][trip % 8][trip / 8]
-    std::vector<uint16_t> offs;              // same indexing: ring row of the X row to read
+    std::vector<double> vals;                // per batch of 16 trips = 4 units: [unit / 2][slot 16][quad lane 4][unit % 2]
+                                             // (lane (slot, quad lane) holds the slot's trip 4 unit + quad lane of every unit)
+    std::vector<uint16_t> offs;              // per batch: [slot 16][quad lane 4][unit 4]: ring row of the X row to read
     std::vector<int32_t> flush_rows;         // first row (of the wave's 8 x G rows: + g * 64 * ... see kernel) per flush
     // statistics
     int max_units_per_step = 0;              // the busiest (wave, step)
     int64_t trips = 0;                       // lock-step trips over all programs
     int64_t entries = 0;                     // = nnz when feasible
-    double efficiency = 0.0;                 // nnz / (8 * trips)
+    double efficiency = 0.0;                 // nnz / (16 * trips)
     double staged_rows_per_row = 0.0;        // X rows staged per matrix row and chunk (1 + window / R for a band)
     std::string why;                         // reason when not feasible
 };

@@ -35,6 +35,7 @@ class SweepPlan:
         _lib.check(lib.rails_sweep_plan_info(h, ii, dd), "rails_sweep_plan_info")
         self.iinfo = np.array(list(ii), dtype=np.int64)
         self.waves, self.groups, self.seg_rows, self.nseg, self.parts, self.phases, self.codes_per_step, self.trips, self.nnz, self.batches = [int(v) for v in ii[:10]]
+        self.slots = int(ii[11])
         self.efficiency, self.staged_rows_per_row = dd[0], dd[1]
         for which, (name, dt) in enumerate(_ARRAYS):
             p = C.c_void_p()
