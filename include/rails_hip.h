@@ -150,11 +150,13 @@ int rails_csr_sweep_stats(rails_csr *A, int nc, double *out);
 const char *rails_csr_last_kernel(const rails_csr *A);
 
 /* Host-side schedule of the sweep kernel (rails_amd/csrc/sweep_plan.h), exposed for tests and diagnostics: no device is
- * touched.  params = {waves, groups, rows per step, ring segments, parts, phases} or NULL for the kernel's own geometry.
- * info: iinfo[0..5] = params, [6] entries per step record, [7] lock-step trips, [8] nnz, [9] batches; [10] units in the busiest (wave, step), [11] slots per wave; dinfo[0] = slot
- * efficiency nnz / (slots x trips), dinfo[1] = X rows staged per matrix row and column chunk.  rails_sweep_plan_array lends the
+ * touched.  params = {waves, groups, rows per step, ring segments, parts, phases, segments being filled at any time} (7
+ * entries) or NULL for the kernel's own geometry.
+ * info (iinfo has room for 16): iinfo[0..5] = params, [6] entries per step record, [7] lock-step trips, [8] nnz, [9] batches,
+ * [10] units in the busiest (wave, step), [11] slots per wave, [12] segments being filled; dinfo[0] = slot efficiency
+ * nnz / (slots x trips), dinfo[1] = X rows staged per matrix row and column chunk.  rails_sweep_plan_array lends the
  * arrays of the plan (which = 0 part_row0 i64, 1 sweep0 i64, 2 nsteps i32, 3 hdr_off i64, 4 batch_off i64, 5 flush_off i64,
- * 6 codes u16, 7 vals f64, 8 offs u16, 9 flush_rows i32); they live until rails_sweep_plan_destroy. */
+ * 6 codes u32, 7 vals f64, 8 offs u16, 9 flush_rows i32); they live until rails_sweep_plan_destroy. */
 typedef struct rails_sweep_plan rails_sweep_plan;
 int rails_sweep_plan_create(int64_t m, int64_t ncols, const int64_t *rowptr, const int32_t *col, const double *val,
                             const int *params, rails_sweep_plan **out);

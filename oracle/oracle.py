@@ -199,13 +199,14 @@ class Oracle:
         X = _f(X)
         Y = np.full((plan.m, 16 * n_chunks), np.nan, order="F")
         u16p = C.POINTER(C.c_uint16)
+        u32p = C.POINTER(C.c_uint32)
         fn = self.lib.orc_sweep_interpret
         fn.restype = C.c_int
-        fn.argtypes = [_i64p, _i64p, _i64p, _i32p, _i64p, _i64p, _i64p, u16p, _dp, u16p, _i32p, C.c_int64, C.c_int64, C.c_int, _dp, C.c_int64,
+        fn.argtypes = [_i64p, _i64p, _i64p, _i32p, _i64p, _i64p, _i64p, u32p, _dp, u16p, _i32p, C.c_int64, C.c_int64, C.c_int, _dp, C.c_int64,
                        _dp, C.c_int64]
         rc = fn(plan.iinfo.ctypes.data_as(_i64p), plan.part_row0.ctypes.data_as(_i64p), plan.sweep0.ctypes.data_as(_i64p),
                 plan.nsteps.ctypes.data_as(_i32p), plan.hdr_off.ctypes.data_as(_i64p), plan.batch_off.ctypes.data_as(_i64p),
-                plan.flush_off.ctypes.data_as(_i64p), plan.codes.ctypes.data_as(u16p), plan.vals.ctypes.data_as(_dp),
+                plan.flush_off.ctypes.data_as(_i64p), plan.codes.ctypes.data_as(u32p), plan.vals.ctypes.data_as(_dp),
                 plan.offs.ctypes.data_as(u16p), plan.flush_rows.ctypes.data_as(_i32p), plan.m, plan.ncols, n_chunks, _p(X), X.shape[0],
                 _p(Y), Y.shape[0])
         return rc, Y

@@ -971,12 +971,13 @@ int orc_solve(int m, const double *Adense, int lda, const int64_t *rp, const int
 // -3 row never written, -4 trips left in a program's stream.
 // ----------------------------------------------------------------------------
 int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const int64_t *sweep0, const int32_t *nsteps,
-                        const int64_t *hdr_off, const int64_t *batch_off, const int64_t *flush_off, const uint16_t *codes,
+                        const int64_t *hdr_off, const int64_t *batch_off, const int64_t *flush_off, const uint32_t *codes,
                         const double *vals, const uint16_t *offs, const int32_t *flush_rows, int64_t m, int64_t ncols, int n_chunks,
                         const double *X, int64_t ldx, double *Y, int64_t ldy)
 {
     const int W = (int)iinfo[0], G = (int)iinfo[1], SEG = (int)iinfo[2], NSEG = (int)iinfo[3], parts = (int)iinfo[4], P = (int)iinfo[5];
     const int CPS = (int)iinfo[6]; // entries per (program, step) record
+    const int AHEAD = (int)iinfo[12]; // segments being refilled at any time
     const int SLOTS = (int)iinfo[11]; // rows of a group in one wave (16: a slot is a quad of lanes)
     std::vector<int> written((size_t)m * n_chunks, 0);
     int rc = 0;
@@ -990,13 +991,23 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
                     std::fill(acc.begin(), acc.end(), 0.0);
                     int64_t trip = 0, fl = 0;
                     for (int k = 0; k < nsteps[x]; ++k)
-                        for (int ci = 1; ci <= (int)codes[hdr_off[prog] + (int64_t)k * CPS]; ++ci) {
-                            const int code = codes[hdr_off[prog] + (int64_t)k * CPS + ci];
-                            const int g = code & 63;
-                            const int T = (code & 0x80) ? 0 : 4;
-                            if (g >= G || ci >= CPS) {
+                        for (int ci = 1; ci <= (int)(codes[hdr_off[prog] + (int64_t)k * CPS] & 0xff); ++ci) {
+                            const uint32_t *rec = codes + hdr_off[prog] + (int64_t)k * CPS;
+                            const int n = (int)(rec[0] & 0xff);
+                            const uint32_t code = rec[ci];
+                            const int g = (int)(code & 0xff) / 8;
+                            const int T = (code & 0x200) ? 0 : 4;
+                            if (g >= G || ci >= CPS || (code & 7)) {
 #pragma omp atomic write
                                 rc = -1;
+                                continue;
+                            }
+                            // the flags the kernel branches on: last entry of the step; the next entry (for the header: the first) has no trips
+                            const bool last = ci == n, next_none = ci < n && (rec[ci + 1] & 0x200);
+                            if (((code & 0x400) != 0) != last || ((code & 0x800) != 0) != next_none ||
+                                (ci == 1 && ((rec[0] & 0x800) != 0) != ((code & 0x200) != 0)) || ((code & 0x200) && !(code & 0x100))) {
+#pragma omp atomic write
+                                rc = -5;
                                 continue;
                             }
                             for (int t = 0; t < T; ++t, ++trip) {
@@ -1009,7 +1020,7 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
                                     const int seg = o / SEG;
                                     const int back = ((k - seg) % NSEG + NSEG) % NSEG; // steps since that segment was filled
                                     const int kk = k - back;
-                                    if (seg >= NSEG || kk < 0 || back > NSEG - 2) {
+                                    if (seg >= NSEG || kk < 0 || back > NSEG - 1 - AHEAD) {
 #pragma omp atomic write
                                         rc = -1;
                                         continue;
@@ -1020,7 +1031,7 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
                                     for (int c = 0; c < 16; ++c) a[c] += v * X[xrow + (int64_t)(q * 16 + c) * ldx];
                                 }
                             }
-                            if (code & 0x40) {
+                            if (code & 0x100) {
                                 const int64_t row0 = flush_rows[flush_off[prog] + fl++];
                                 for (int s = 0; s < SLOTS; ++s) {
                                     const int64_t row = row0 + s;

@@ -61,6 +61,17 @@ constexpr int SWEEP_ACC0 = 24;
 // (the assembly names registers above the compiler's share and M0 in its clobber lists on purpose)
 #pragma clang diagnostic ignored "-Winline-asm"
 #define RAILS_SW_NAME k_spmm_sweep
+#define RAILS_SW_ABLATE 0 /* the product kernel: no experiment switches */
+#define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
+#define RAILS_SW_FMA(TEXT) TEXT
+#define RAILS_SW_VMWAIT(TEXT) TEXT
+#define RAILS_SW_IDX(TEXT) TEXT
+#define RAILS_SW_DPPSFX "_dpp"
+#define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#include "spmm_sweep_kernel.inc"
+// the full kernel with the run-time experiment switches (RAILS_SWEEP_ABLATE & 7: no LDS-DMA / no trips / no barriers)
+#define RAILS_SW_NAME k_spmm_sweep_switches
+#define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -70,6 +81,7 @@ constexpr int SWEEP_ACC0 = 24;
 #include "spmm_sweep_kernel.inc"
 // experiments: without the ring-row reads / the multiply-adds / the waits for the schedule stream
 #define RAILS_SW_NAME k_spmm_sweep_noread
+#define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_READ(DST, ADDR) ""
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -78,6 +90,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_nofma
+#define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) ""
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -86,6 +99,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_nowait
+#define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) ""
@@ -94,6 +108,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_noidx
+#define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -102,6 +117,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_bare
+#define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_READ(DST, ADDR) ""
 #define RAILS_SW_FMA(TEXT) ""
 #define RAILS_SW_VMWAIT(TEXT) ""
@@ -110,6 +126,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_nodpp
+#define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -122,7 +139,7 @@ struct DevPlan {
     rails_sweep_plan host; // kept for its small arrays and statistics (the big arrays are released after the upload)
     int64_t *part_row0 = nullptr, *sweep0 = nullptr, *hdr_off = nullptr, *batch_off = nullptr, *flush_off = nullptr;
     int32_t *nsteps = nullptr, *flush_rows = nullptr;
-    uint16_t *codes = nullptr;
+    uint32_t *codes = nullptr;
     double *vals = nullptr;
     uint16_t *offs = nullptr;
     bool ok = false;
@@ -194,7 +211,8 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
         prm.nseg = NSEG;
         prm.parts = 8;
         prm.phases = 32 / n_chunks;
-        if (getenv("RAILS_SWEEP_LEVEL")) prm.level = atoi(getenv("RAILS_SWEEP_LEVEL")); // experiments: 0 = no levelling of the units over the steps
+        if (getenv("RAILS_SWEEP_LEVEL")) prm.level = atoi(getenv("RAILS_SWEEP_LEVEL")); // experiments: 0 = no levelling of the waves
+        if (getenv("RAILS_SWEEP_MIN_FILL")) prm.level_min_fill = atoi(getenv("RAILS_SWEEP_MIN_FILL"));
         if (rails_sweep_plan_build(prm, A->m, A->ncols_ext, A->h_rowptr.data(), A->h_col.data(), A->h_val.data(), d->host)) {
             RAILS_TRY(up(c, &d->part_row0, d->host.part_row0));
             RAILS_TRY(up(c, &d->sweep0, d->host.sweep0));
@@ -209,7 +227,7 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
             RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
             std::vector<double>().swap(d->host.vals);
             std::vector<uint16_t>().swap(d->host.offs);
-            std::vector<uint16_t>().swap(d->host.codes);
+            std::vector<uint32_t>().swap(d->host.codes);
             d->ok = true;
         }
     }
@@ -242,7 +260,12 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
     case 4: RAILS_SWEEP_LAUNCH(k_spmm_sweep_noidx); break;
     case 5: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nodpp); break;
     case 6: RAILS_SWEEP_LAUNCH(k_spmm_sweep_bare); break;
-    default: RAILS_SWEEP_LAUNCH(k_spmm_sweep); break;
+    default:
+        if (ablate)
+            RAILS_SWEEP_LAUNCH(k_spmm_sweep_switches);
+        else
+            RAILS_SWEEP_LAUNCH(k_spmm_sweep);
+        break;
     }
     RAILS_HIP_CHECK(hipGetLastError());
     A->last_kernel = "k_spmm_sweep";

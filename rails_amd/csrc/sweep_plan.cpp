@@ -14,7 +14,6 @@ constexpr int SLOTS = 16; // rows of a group in one wave: a slot is a quad of la
 // the schedule of one group: its units (four trips each, or a flush without trips) in execution order
 struct GroupSchedule {
     std::vector<int> step;        // per unit: the step it runs in
-    std::vector<int> earliest;    // per unit: the first step at which all its X rows are in the ring
     std::vector<uint8_t> flags;   // per unit: 1 = the group's partial sums go to Y afterwards, 2 = no trips
     std::vector<double> val;      // [units with trips][4][SLOTS]
     std::vector<uint16_t> off;
@@ -33,69 +32,91 @@ struct Ctx {
     int64_t nblocks;
 };
 
-// schedule of one (phase, wave, group) of a part; false = not feasible
-bool schedule_group(const Ctx &c, int phase, int wave, int g, GroupSchedule &out, std::string &why)
-{
-    const rails_sweep_params &P = *c.prm;
-    const int SEG = P.seg_rows, NSEG = P.nseg;
-    const int ring = SEG * NSEG;
-    out.step.clear();
-    out.earliest.clear();
-    out.flags.clear();
-    out.val.clear();
-    out.off.clear();
-    out.flush.clear();
-    int64_t bj = phase; // current block of this workgroup
-    // state of the current block
-    int64_t p[SLOTS], pe[SLOTS]; // next / end nonzero of each slot's row
+// One group of a wave (SLOTS rows of every block of the wave's workgroup) on its way through the sweep.  Per step: look() says what
+// has arrived and what cannot wait; run() forms the units (every slot takes up to four of its arrived nonzeros per unit, in column
+// order) and moves on to the workgroup's next block when the rows are done.
+struct GroupRun {
+    const Ctx *c = nullptr;
+    int phase = 0, wave = 0, g = 0;
+    GroupSchedule out;
+    int64_t bj = 0;                // current block of this workgroup
+    int64_t p[SLOTS], pe[SLOTS];   // next / end nonzero of each slot's row
     int64_t last_pos[SLOTS];
     bool loaded = false, any_valid = false;
-    int64_t cur_row0 = 0;
-    auto load_block = [&](int64_t j) {
-        cur_row0 = c.r0 + j * c.R + (int64_t)g * P.waves * SLOTS + (int64_t)wave * SLOTS;
+    int64_t cur_row0 = 0, next_first = INT64_MAX;
+    // what look() found for the current step
+    int need = 0;                  // trips that have to run in this step
+    int full = 0;                  // trips every slot with work left can fill (no idle slots: free of waste)
+    int avail[SLOTS];              // arrived nonzeros per slot
+    int64_t lo = 0, hi = 0;
+
+    int64_t row0_of(int64_t j) const { return c->r0 + j * c->R + (int64_t)g * c->prm->waves * SLOTS + (int64_t)wave * SLOTS; }
+
+    void start(const Ctx &ctx, int ph, int w, int group)
+    {
+        c = &ctx;
+        phase = ph;
+        wave = w;
+        g = group;
+        out = GroupSchedule();
+        bj = ph;
+        loaded = false;
+        need = full = 0;
+    }
+
+    void load_block(int64_t j)
+    {
+        cur_row0 = row0_of(j);
         any_valid = false;
         for (int s = 0; s < SLOTS; ++s) {
             const int64_t row = cur_row0 + s;
             last_pos[s] = -1;
-            if (row < c.r1 && row < c.r0 + (j + 1) * c.R) {
-                p[s] = c.rowptr[row];
-                pe[s] = c.rowptr[row + 1];
+            if (row < c->r1 && row < c->r0 + (j + 1) * c->R) {
+                p[s] = c->rowptr[row];
+                pe[s] = c->rowptr[row + 1];
                 any_valid = true;
             } else
                 p[s] = pe[s] = 0;
         }
         loaded = true;
-    };
+    }
+
     // first sweep segment of the first nonzero of block j for this group (INT64_MAX: none)
-    auto first_seg = [&](int64_t j) -> int64_t {
-        if (j >= c.nblocks) return INT64_MAX;
-        const int64_t row0 = c.r0 + j * c.R + (int64_t)g * P.waves * SLOTS + (int64_t)wave * SLOTS;
+    int64_t first_seg(int64_t j) const
+    {
+        if (j >= c->nblocks) return INT64_MAX;
+        const int64_t row0 = row0_of(j);
         int64_t best = INT64_MAX;
         for (int s = 0; s < SLOTS; ++s) {
             const int64_t row = row0 + s;
-            if (row < c.r1 && row < c.r0 + (j + 1) * c.R && c.rowptr[row + 1] > c.rowptr[row])
-                best = std::min<int64_t>(best, ((int64_t)c.col[c.rowptr[row]] - c.sweep0) / SEG);
+            if (row < c->r1 && row < c->r0 + (j + 1) * c->R && c->rowptr[row + 1] > c->rowptr[row])
+                best = std::min<int64_t>(best, ((int64_t)c->col[c->rowptr[row]] - c->sweep0) / c->prm->seg_rows);
         }
         return best;
-    };
-    int64_t next_first = INT64_MAX;
-    for (int k = 0; k < c.nsteps; ++k) {
+    }
+
+    bool look(int k, std::string &why)
+    {
+        const rails_sweep_params &P = *c->prm;
+        const int SEG = P.seg_rows, NSEG = P.nseg;
+        need = full = 0;
+        for (int s = 0; s < SLOTS; ++s) avail[s] = 0;
         if (!loaded) {
-            if (bj >= c.nblocks) break;
+            if (bj >= c->nblocks) return true;
             load_block(bj);
             // the next block WITH nonzeros bounds how long this one may take
             next_first = INT64_MAX;
-            for (int64_t j = bj + P.phases; j < c.nblocks && next_first == INT64_MAX; j += P.phases) next_first = first_seg(j);
+            for (int64_t j = bj + P.phases; j < c->nblocks && next_first == INT64_MAX; j += P.phases) next_first = first_seg(j);
         }
-        const int64_t hi = (int64_t)(k + 1) * SEG;
-        const int64_t lo = (int64_t)(k - NSEG + 2) * SEG;                            // readable: [lo, hi)
-        const int64_t lo_next = (k == c.nsteps - 1) ? INT64_MAX : lo + SEG;          // gone after this step
+        hi = (int64_t)(k + 1) * SEG;
+        lo = (int64_t)(k - NSEG + 1 + P.ahead) * SEG;                                 // readable: [lo, hi)
+        const int64_t lo_next = (k == c->nsteps - 1) ? INT64_MAX : lo + SEG;          // gone after this step
         int forced = 0, remaining = 0, ready = INT_MAX;
         bool all_available = true;
         for (int s = 0; s < SLOTS; ++s) {
             int f = 0, av = 0;
             for (int64_t q = p[s]; q < pe[s]; ++q) {
-                const int64_t pos = (int64_t)c.col[q] - c.sweep0;
+                const int64_t pos = (int64_t)c->col[q] - c->sweep0;
                 if (pos < lo) {
                     why = "a nonzero lost its X row before it was consumed (columns of a row not sorted?)";
                     return false;
@@ -104,25 +125,40 @@ bool schedule_group(const Ctx &c, int phase, int wave, int g, GroupSchedule &out
                 ++av;
                 if (pos < lo_next) ++f;
             }
+            avail[s] = av;
             forced = std::max(forced, f);
             if (pe[s] > p[s]) ready = std::min(ready, av);
             remaining = std::max<int>(remaining, (int)(pe[s] - p[s]));
-            if (pe[s] > p[s] && (int64_t)c.col[pe[s] - 1] - c.sweep0 >= hi) all_available = false;
+            if (pe[s] > p[s] && (int64_t)c->col[pe[s] - 1] - c->sweep0 >= hi) all_available = false;
         }
         // the block has to be done before the first X row of the workgroup's next block leaves the ring
-        const bool must_finish = next_first != INT64_MAX && (int64_t)k >= next_first + NSEG - 3;
-        // what has to go now, or more where every slot with work left can fill whole units (no idle slots: spreads bursts for free)
-        int T = std::max(forced, ready == INT_MAX ? 0 : ready / 4 * 4);
+        const bool must_finish = next_first != INT64_MAX && (int64_t)k >= next_first + NSEG - 2 - P.ahead;
+        need = forced;
+        full = ready == INT_MAX ? 0 : ready / 4 * 4;
         if (must_finish || remaining == 0) {
             if (!all_available) {
                 why = "the column window of a row block is wider than (phases - 1) blocks";
                 return false;
             }
-            T = remaining;
+            need = remaining;
         }
-        // trips come in units of four (the kernel's unit: four ring rows in flight, then four multiply-adds per lane)
-        const int units = (T + 3) / 4;
-        T = units * 4;
+        return true;
+    }
+
+    // nonzeros unit number n of this step would consume (n = 0: the first)
+    int fill_of_unit(int n) const
+    {
+        int f = 0;
+        for (int s = 0; s < SLOTS; ++s) f += std::min(std::max(avail[s] - 4 * n, 0), 4);
+        return f;
+    }
+
+    bool run(int k, int units, std::string &why)
+    {
+        if (!loaded) return true;
+        const rails_sweep_params &P = *c->prm;
+        const int SEG = P.seg_rows, NSEG = P.nseg;
+        const int ring = SEG * NSEG;
         if (units > 127) {
             why = "more than 508 nonzeros of one row inside one ring of X rows";
             return false;
@@ -130,24 +166,24 @@ bool schedule_group(const Ctx &c, int phase, int wave, int g, GroupSchedule &out
         for (int u = 0; u < units; ++u) {
             double v[4][SLOTS];
             int64_t o[4][SLOTS];
-            int64_t first_real = -1, newest = -1;
+            int64_t first_real = -1;
             for (int t = 0; t < 4; ++t)
                 for (int s = 0; s < SLOTS; ++s) {
                     v[t][s] = 0.0;
                     o[t][s] = -1;
                     if (p[s] < pe[s]) {
-                        const int64_t pos = (int64_t)c.col[p[s]] - c.sweep0;
+                        const int64_t pos = (int64_t)c->col[p[s]] - c->sweep0;
                         if (pos < hi) {
-                            v[t][s] = c.val[p[s]];
+                            v[t][s] = c->val[p[s]];
                             o[t][s] = pos;
                             ++p[s];
                             if (first_real < 0) first_real = pos;
-                            newest = std::max(newest, pos);
                         }
                     }
                 }
+            if (first_real < 0) break; // nothing left that has arrived
             // an idle slot multiplies an X row by zero: the row of its own previous nonzero while that is still in the ring, else
-            // the first row this unit reads anyway (both are there at whatever step the unit ends up running)
+            // the first row this unit reads anyway
             for (int t = 0; t < 4; ++t)
                 for (int s = 0; s < SLOTS; ++s) {
                     if (o[t][s] >= 0)
@@ -158,16 +194,14 @@ bool schedule_group(const Ctx &c, int phase, int wave, int g, GroupSchedule &out
                     out.off.push_back((uint16_t)(o[t][s] % ring));
                 }
             out.step.push_back(k);
-            out.earliest.push_back((int)(newest / SEG));
             out.flags.push_back(0);
         }
         bool done = true;
         for (int s = 0; s < SLOTS; ++s) done = done && p[s] == pe[s];
         if (done) {
             if (any_valid) {
-                if (units == 0) { // rows without (remaining) nonzeros: a flush of its own, tied to this step
+                if (out.step.empty() || out.step.back() != k || (out.flags.back() & 1)) { // nothing ran in this step for this block: a flush of its own
                     out.step.push_back(k);
-                    out.earliest.push_back(k);
                     out.flags.push_back(2);
                 }
                 out.flags.back() |= 1;
@@ -176,12 +210,67 @@ bool schedule_group(const Ctx &c, int phase, int wave, int g, GroupSchedule &out
             loaded = false;
             bj += P.phases;
         }
+        return true;
     }
-    if (loaded || bj < c.nblocks) {
-        // blocks left over after the last step: only possible for rows without nonzeros beyond the swept range
-        why = "row blocks left after the last sweep step";
-        return false;
+
+    bool left_over() const { return loaded || bj < c->nblocks; }
+};
+
+// The schedule of one workgroup (W waves x G groups) of a part.  All its waves meet at a barrier every step, so a step costs what its
+// busiest wave costs.  Per step: every group runs what cannot wait (X rows about to leave the ring, the end of a block) and what is
+// free of waste (units without idle slots); the busiest wave's number of units is then what the step costs anyway, and every other wave
+// fills up to it with the units that consume the most of what has arrived -- work that would otherwise be forced on it in a later step,
+// where it might be the busiest one.  (Every unit run as late as possible: the sum over the steps of the busiest wave's units is 1.37 x
+// the mean wave's.)
+bool schedule_workgroup(const Ctx &c, int phase, std::vector<std::vector<GroupRun>> &runs, std::string &why)
+{
+    const rails_sweep_params &P = *c.prm;
+    const int W = P.waves, G = P.groups;
+    const int cap = RAILS_SWEEP_CODES - 2;
+    for (int w = 0; w < W; ++w)
+        for (int g = 0; g < G; ++g) runs[w][g].start(c, phase, w, g);
+    std::vector<int> units((size_t)W * G), load(W);
+    for (int k = 0; k < c.nsteps; ++k) {
+        int level = 0;
+        for (int w = 0; w < W; ++w) {
+            load[w] = 0;
+            for (int g = 0; g < G; ++g) {
+                GroupRun &r = runs[w][g];
+                if (!r.look(k, why)) return false;
+                units[(size_t)w * G + g] = (std::max(r.need, r.full) + 3) / 4;
+                load[w] += units[(size_t)w * G + g];
+            }
+            level = std::max(level, load[w]);
+        }
+        for (int w = 0; w < W; ++w) {
+            while (P.level && load[w] < level) {
+                int best = -1, best_fill = P.level_min_fill - 1;
+                for (int g = 0; g < G; ++g) {
+                    const int f = runs[w][g].fill_of_unit(units[(size_t)w * G + g]);
+                    if (f > best_fill) {
+                        best = g;
+                        best_fill = f;
+                    }
+                }
+                if (best < 0) break;
+                ++units[(size_t)w * G + best];
+                ++load[w];
+            }
+            if (load[w] + G > cap) {
+                why = "more units of one wave in one step than a step's record holds";
+                return false;
+            }
+            for (int g = 0; g < G; ++g)
+                if (!runs[w][g].run(k, units[(size_t)w * G + g], why)) return false;
+        }
     }
+    for (int w = 0; w < W; ++w)
+        for (int g = 0; g < G; ++g)
+            if (runs[w][g].left_over()) {
+                // blocks left over after the last step: only possible for rows without nonzeros beyond the swept range
+                why = "row blocks left after the last sweep step";
+                return false;
+            }
     return true;
 }
 
@@ -196,7 +285,7 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
     plan.ncols = ncols;
     plan.nnz = rowptr[m];
     const int W = prm.waves, G = prm.groups, P = prm.phases, SEG = prm.seg_rows;
-    if (W < 1 || G < 1 || G > 64 || P < 1 || prm.parts < 1 || prm.nseg < 3 || SEG < 8 || SEG % 8 || (int64_t)SEG * prm.nseg > 65536) {
+    if (W < 1 || G < 1 || G > 31 || P < 1 || prm.parts < 1 || prm.ahead < 1 || prm.nseg < prm.ahead + 2 || SEG < 8 || SEG % 8 || (int64_t)SEG * prm.nseg > 65536) {
         plan.why = "bad parameters";
         return false;
     }
@@ -217,7 +306,7 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                 return false;
             }
     int64_t staged = 0;
-    std::vector<std::vector<GroupSchedule>> all(W, std::vector<GroupSchedule>(G));
+    std::vector<std::vector<GroupRun>> runs(W, std::vector<GroupRun>(G));
     for (int x = 0; x < prm.parts; ++x) {
         Ctx c;
         c.prm = &prm;
@@ -238,79 +327,36 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
         c.sweep0 = cmin;
         // at least one step per block of a workgroup, so that blocks of rows without nonzeros still get their zeros written
         const int64_t by_blocks = (c.nblocks + P - 1) / P;
-        // NSEG - 2 steps beyond the last X row, so that the last nonzeros are consumed at the pace of all the others
-        c.nsteps = (int)std::max<int64_t>((cmax - cmin) / SEG + 1 + (prm.nseg - 2), by_blocks);
+        // NSEG - 1 - ahead steps beyond the last X row, so that the last nonzeros are consumed at the pace of all the others
+        c.nsteps = (int)std::max<int64_t>((cmax - cmin) / SEG + 1 + (prm.nseg - 1 - prm.ahead), by_blocks);
         plan.sweep0[x] = c.sweep0;
         plan.nsteps[x] = c.nsteps;
         staged += (int64_t)c.nsteps * SEG * P;
         for (int ph = 0; ph < P; ++ph) {
-            for (int w = 0; w < W; ++w)
-                for (int g = 0; g < G; ++g)
-                    if (!schedule_group(c, ph, w, g, all[w][g], plan.why)) return false;
-            // Level the work of the workgroup's waves step by step: all of them meet at a barrier every step, so a step costs what
-            // its busiest wave costs (unlevelled: the sum over the steps of the busiest wave's units is 1.32 x the mean wave's).  The
-            // schedule above runs a unit as late as its X rows allow; it may run earlier, down to the step in which the last of its
-            // rows arrives, as long as the units of its group stay in order.  From the last step backwards, a wave above the step's
-            // mean over the waves hands the first unit of a group to the step before.
-            if (prm.level) {
-                std::vector<std::vector<int>> load(W, std::vector<int>(c.nsteps, 0));
-                for (int w = 0; w < W; ++w)
-                    for (int g = 0; g < G; ++g)
-                        for (size_t u = 0; u < all[w][g].step.size(); ++u)
-                            if (!(all[w][g].flags[u] & 2)) ++load[w][all[w][g].step[u]];
-                std::vector<size_t> head(G);
-                for (int k = c.nsteps - 1; k >= 1; --k) {
-                    int sum = 0;
-                    for (int w = 0; w < W; ++w) sum += load[w][k];
-                    const int target = (sum + W - 1) / W;
-                    for (int w = 0; w < W; ++w) {
-                        if (load[w][k] <= target) continue;
-                        std::vector<GroupSchedule> &gs = all[w];
-                        for (int g = 0; g < G; ++g) {
-                            size_t u = 0;
-                            while (u < gs[g].step.size() && gs[g].step[u] < k) ++u;
-                            head[g] = u;
-                        }
-                        bool moved = true;
-                        while (load[w][k] > target && moved) {
-                            moved = false;
-                            for (int g = 0; g < G && load[w][k] > target; ++g) {
-                                const size_t u = head[g];
-                                if (u >= gs[g].step.size() || gs[g].step[u] != k || (gs[g].flags[u] & 2) || gs[g].earliest[u] > k - 1) continue;
-                                gs[g].step[u] = k - 1;
-                                ++head[g];
-                                --load[w][k];
-                                ++load[w][k - 1];
-                                moved = true;
-                            }
-                        }
-                    }
-                }
-            }
+            if (!schedule_workgroup(c, ph, runs, plan.why)) return false;
             for (int w = 0; w < W; ++w) {
                 const int64_t prog = ((int64_t)x * P + ph) * W + w;
-                std::vector<GroupSchedule> &gs = all[w];
-                // serialise: per step a record of RAILS_SWEEP_CODES 16-bit entries: [0] = n, then one entry per unit of four trips (or per
-                // flush without trips): group | flush after << 6 | no trips << 7, in group order; the trips in the same order, 16
-                // trips per batch: lane q of a slot holds trips q and q + 8 of the batch
+                std::vector<GroupRun> &gr = runs[w];
+                // serialise: per step a record of RAILS_SWEEP_CODES 32-bit entries (sweep_plan.h): a header with the number of entries, then
+                // one entry per unit of four trips (or per flush without trips), in group order; the trips in the same order
                 plan.hdr_off[prog] = (int64_t)plan.codes.size();
-                plan.codes.resize(plan.codes.size() + (size_t)c.nsteps * RAILS_SWEEP_CODES, (uint16_t)0);
-                uint16_t *h = plan.codes.data() + plan.hdr_off[prog];
+                plan.codes.resize(plan.codes.size() + (size_t)c.nsteps * RAILS_SWEEP_CODES, 0u);
+                uint32_t *h = plan.codes.data() + plan.hdr_off[prog];
                 plan.batch_off[prog] = (int64_t)(plan.vals.size() / 256);
                 plan.flush_off[prog] = (int64_t)plan.flush_rows.size();
                 std::vector<size_t> up(G, 0), tp(G, 0), fp(G, 0); // per group: next unit / next unit with trips / next flush
                 int64_t trip = 0;                                  // trips of this wave so far
                 for (int k = 0; k < c.nsteps; ++k) {
                     int n = 0;
-                    uint16_t *rec = h + (size_t)k * RAILS_SWEEP_CODES;
+                    uint32_t *rec = h + (size_t)k * RAILS_SWEEP_CODES;
                     for (int g = 0; g < G; ++g)
-                        while (up[g] < gs[g].step.size() && gs[g].step[up[g]] == k) {
-                            const uint8_t fl = gs[g].flags[up[g]++];
+                        while (up[g] < gr[g].out.step.size() && gr[g].out.step[up[g]] == k) {
+                            const uint8_t fl = gr[g].out.flags[up[g]++];
                             if (n + 1 > RAILS_SWEEP_CODES - 1) {
-                                plan.why = "more than 127 units of one wave in one step (step " + std::to_string(k) + " of " + std::to_string(c.nsteps) + ", part " + std::to_string(x) + ")";
+                                plan.why = "more than 63 units of one wave in one step (step " + std::to_string(k) + " of " + std::to_string(c.nsteps) + ", part " + std::to_string(x) + ")";
                                 return false;
                             }
-                            rec[1 + n++] = (uint16_t)(g | ((fl & 1) ? 0x40 : 0) | ((fl & 2) ? 0x80 : 0));
+                            rec[1 + n++] = (uint32_t)(g * 8) | ((fl & 1) ? RAILS_SWEEP_FLUSH : 0u) | ((fl & 2) ? RAILS_SWEEP_NO_TRIPS : 0u);
                             if (!(fl & 2)) {
                                 for (int t = 0; t < 4; ++t, ++trip) {
                                     const int64_t b = plan.batch_off[prog] + trip / 16;
@@ -324,15 +370,19 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                                     const int tt = (int)(trip % 16), unit = tt / 4, ql = tt % 4;
                                     for (int s = 0; s < SLOTS; ++s) {
                                         const size_t lane = (size_t)s * 4 + ql;
-                                        plan.vals[(size_t)b * 256 + (size_t)(unit / 2) * 128 + lane * 2 + (unit % 2)] = gs[g].val[(tp[g] * 4 + t) * SLOTS + s];
-                                        plan.offs[(size_t)b * 256 + lane * 4 + unit] = gs[g].off[(tp[g] * 4 + t) * SLOTS + s];
+                                        plan.vals[(size_t)b * 256 + (size_t)(unit / 2) * 128 + lane * 2 + (unit % 2)] = gr[g].out.val[(tp[g] * 4 + t) * SLOTS + s];
+                                        plan.offs[(size_t)b * 256 + lane * 4 + unit] = gr[g].out.off[(tp[g] * 4 + t) * SLOTS + s];
                                     }
                                 }
                                 ++tp[g];
                             }
-                            if (fl & 1) plan.flush_rows.push_back(gs[g].flush[fp[g]++]);
+                            if (fl & 1) plan.flush_rows.push_back(gr[g].out.flush[fp[g]++]);
                         }
-                    rec[0] = (uint16_t)n;
+                    // what the kernel branches on after a unit: anything but "go on with the next entry"
+                    rec[0] = (uint32_t)n;
+                    if (n) rec[n] |= RAILS_SWEEP_LAST;
+                    for (int e = 1; e <= n; ++e)
+                        if (rec[e] & RAILS_SWEEP_NO_TRIPS) rec[e - 1] |= RAILS_SWEEP_NEXT_NO_TRIPS;
                     plan.max_units_per_step = std::max(plan.max_units_per_step, n);
                 }
                 plan.trips += trip;
@@ -368,7 +418,9 @@ extern "C" int rails_sweep_plan_create(int64_t m, int64_t ncols, const int64_t *
         prm.nseg = params[3];
         prm.parts = params[4];
         prm.phases = params[5];
-        if (getenv("RAILS_SWEEP_LEVEL")) prm.level = atoi(getenv("RAILS_SWEEP_LEVEL"));
+        prm.ahead = params[6];
+        if (getenv("RAILS_SWEEP_LEVEL")) prm.level = atoi(getenv("RAILS_SWEEP_LEVEL")); // experiments: 0 = no levelling of the waves
+        if (getenv("RAILS_SWEEP_MIN_FILL")) prm.level_min_fill = atoi(getenv("RAILS_SWEEP_MIN_FILL"));
     }
     rails_sweep_plan *pl = new rails_sweep_plan();
     if (!rails_sweep_plan_build(prm, m, ncols, rowptr, col, val, *pl)) {
@@ -400,6 +452,7 @@ extern "C" int rails_sweep_plan_info(const rails_sweep_plan *pl, int64_t *iinfo,
     iinfo[8] = pl->nnz;
     iinfo[9] = (int64_t)(pl->vals.size() / 256);
     iinfo[11] = SLOTS;
+    iinfo[12] = pl->p.ahead;
     iinfo[10] = pl->max_units_per_step;
     dinfo[0] = pl->efficiency;
     dinfo[1] = pl->staged_rows_per_row;

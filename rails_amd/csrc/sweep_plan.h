@@ -14,8 +14,9 @@
 //   blocks   a part's rows are cut into blocks of R = G * W * 16 rows; block j belongs to phase j % phases; a
 //            workgroup owns one block at a time: G groups x W waves x 16 slots, one row per slot (a quad of lanes),
 //            16 partial sums per row, four per lane
-//   steps    sweep position s = column - sweep0(part); step k brings positions [k*SEG, (k+1)*SEG) into ring
-//            segment k % NSEG while the lanes may read positions [(k-NSEG+2)*SEG, (k+1)*SEG)
+//   steps    sweep position s = column - sweep0(part); positions [k*SEG, (k+1)*SEG) live in ring segment k % NSEG; they are
+//            asked for at the start of step k - ahead and have arrived at the start of step k, during which the lanes may read
+//            positions [(k-NSEG+1+ahead)*SEG, (k+1)*SEG)
 //   trips    one trip = every slot of a wave consumes at most one nonzero of its row (lock step); trips come in units
 //            of four; per step and group the schedule gives the number of units; a group's partial sums are written
 //            to Y when its block is done
@@ -26,16 +27,24 @@
 #include <string>
 #include <vector>
 
-constexpr int RAILS_SWEEP_CODES = 128; // 16-bit entries per (program, step) record: two per lane of a wave; groups <= 64
+constexpr int RAILS_SWEEP_CODES = 64; // 32-bit entries per (program, step) record, one per lane of a wave: a header, then up to 63 entries
+// An entry = one unit of four trips of a group (or a flush without trips): bits 0-7 = 8 x group (the group's first partial-sum register
+// relative to the first group's); the header: bits 0-7 = number of entries.  Flags (the kernel tests them together after a unit):
+constexpr uint32_t RAILS_SWEEP_FLUSH = 0x100;         // the group's partial sums go to Y after this entry
+constexpr uint32_t RAILS_SWEEP_NO_TRIPS = 0x200;      // the entry has no trips (rows without nonzeros left: only the flush)
+constexpr uint32_t RAILS_SWEEP_LAST = 0x400;          // last entry of the step
+constexpr uint32_t RAILS_SWEEP_NEXT_NO_TRIPS = 0x800; // the next entry has no trips (in the header: the first entry)
 
 struct rails_sweep_params {
     int waves = 8;      // W: waves per workgroup
     int groups = 22;    // G: row groups per wave (each: 16 slots = 16 rows)
     int seg_rows = 256; // SEG: X rows per step
-    int nseg = 5;       // ring segments (NSEG - 1 are readable while one is being filled)
+    int nseg = 5;       // ring segments
+    int ahead = 1;      // segments being filled at any time: step k asks for the rows of step k + ahead (NSEG - ahead are readable)
     int parts = 8;      // row ranges (XCDs)
     int phases = 4;     // workgroups per (part, column chunk)
-    int level = 1;      // level every wave's units over the steps (0: run every unit as late as its X rows allow)
+    int level = 1;      // level the waves of a workgroup step by step (0: every unit as late as its X rows allow)
+    int level_min_fill = 16; // a unit run early to level must consume at least this many nonzeros (of 4 x 16)
 };
 
 struct rails_sweep_plan {
@@ -48,8 +57,7 @@ struct rails_sweep_plan {
     std::vector<int64_t> hdr_off;            // [programs] offset into codes
     std::vector<int64_t> batch_off;          // [programs] first batch (16 trips) in vals / offs
     std::vector<int64_t> flush_off;          // [programs] offset into flush_rows
-    std::vector<uint16_t> codes;             // per (program, step) RAILS_SWEEP_CODES entries: [0] = n, then n units of four trips:
-                                             // group | flush after << 6 | no trips << 7, in group order
+    std::vector<uint32_t> codes;             // per (program, step) RAILS_SWEEP_CODES entries (see above), units in group order
     std::vector<double> vals;                // per batch of 16 trips = 4 units: [unit / 2][slot 16][quad lane 4][unit % 2]
                                              // (lane (slot, quad lane) holds the slot's trip 4 unit + quad lane of every unit)
     std::vector<uint16_t> offs;              // per batch: [slot 16][quad lane 4][unit 4]: ring row of the X row to read

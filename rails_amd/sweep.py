@@ -9,11 +9,11 @@ import numpy as np
 from . import _lib
 
 _ARRAYS = [("part_row0", np.int64), ("sweep0", np.int64), ("nsteps", np.int32), ("hdr_off", np.int64), ("batch_off", np.int64),
-           ("flush_off", np.int64), ("codes", np.uint16), ("vals", np.float64), ("offs", np.uint16), ("flush_rows", np.int32)]
+           ("flush_off", np.int64), ("codes", np.uint32), ("vals", np.float64), ("offs", np.uint16), ("flush_rows", np.int32)]
 
 
 class SweepPlan:
-    """params = (waves, groups, rows per step, ring segments, parts, phases) or None for the kernel's geometry."""
+    """params = (waves, groups, rows per step, ring segments, parts, phases[, segments being filled]) or None for the kernel's geometry."""
 
     def __init__(self, rowptr, col, val, ncols=None, params=None):
         lib = _lib.load()
@@ -25,7 +25,8 @@ class SweepPlan:
         self.ncols = int(m if ncols is None else ncols)
         prm = None
         if params is not None:
-            prm = (C.c_int * 6)(*[int(v) for v in params])
+            params = list(params) + [1] * (7 - len(params))
+            prm = (C.c_int * 7)(*[int(v) for v in params])
         h = C.c_void_p()
         _lib.check(lib.rails_sweep_plan_create(m, self.ncols, rowptr.ctypes.data_as(_lib._i64p), col.ctypes.data_as(_lib._i32p),
                                                val.ctypes.data_as(_lib._dp), prm, C.byref(h)), "rails_sweep_plan_create")
@@ -36,6 +37,7 @@ class SweepPlan:
         self.iinfo = np.array(list(ii), dtype=np.int64)
         self.waves, self.groups, self.seg_rows, self.nseg, self.parts, self.phases, self.codes_per_step, self.trips, self.nnz, self.batches = [int(v) for v in ii[:10]]
         self.slots = int(ii[11])
+        self.ahead = int(ii[12])
         self.efficiency, self.staged_rows_per_row = dd[0], dd[1]
         for which, (name, dt) in enumerate(_ARRAYS):
             p = C.c_void_p()
