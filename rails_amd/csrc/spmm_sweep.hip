@@ -213,6 +213,7 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
         prm.phases = 32 / n_chunks;
         if (getenv("RAILS_SWEEP_LEVEL")) prm.level = atoi(getenv("RAILS_SWEEP_LEVEL")); // experiments: 0 = no levelling of the waves
         if (getenv("RAILS_SWEEP_MIN_FILL")) prm.level_min_fill = atoi(getenv("RAILS_SWEEP_MIN_FILL"));
+        if (getenv("RAILS_SWEEP_SLACK")) prm.level_slack = atoi(getenv("RAILS_SWEEP_SLACK"));
         if (rails_sweep_plan_build(prm, A->m, A->ncols_ext, A->h_rowptr.data(), A->h_col.data(), A->h_val.data(), d->host)) {
             RAILS_TRY(up(c, &d->part_row0, d->host.part_row0));
             RAILS_TRY(up(c, &d->sweep0, d->host.sweep0));
@@ -253,7 +254,7 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
 #define RAILS_SWEEP_LAUNCH(K)                                                                                                                     \
     hipLaunchKernelGGL((K<SWEEP_W, SWEEP_G>), dim3(256), dim3(SWEEP_W * 64), 0, c->stream, a, d->part_row0, d->sweep0, d->nsteps, d->hdr_off, \
                        d->batch_off, d->flush_off, d->codes, d->vals, d->offs, d->flush_rows, X, Xg, Y)
-    switch (ablate >> 4) {
+    switch ((ablate >> 4) & 15) {
     case 1: RAILS_SWEEP_LAUNCH(k_spmm_sweep_noread); break;
     case 2: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nofma); break;
     case 3: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nowait); break;

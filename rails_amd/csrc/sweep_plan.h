@@ -29,7 +29,7 @@
 
 constexpr int RAILS_SWEEP_CODES = 64; // 32-bit entries per (program, step) record, one per lane of a wave: a header, then up to 63 entries
 // An entry = one unit of four trips of a group (or a flush without trips): bits 0-7 = 8 x group (the group's first partial-sum register
-// relative to the first group's); the header: bits 0-7 = number of entries.  Flags (the kernel tests them together after a unit):
+// relative to the first group's); the header: bits 0-7 = number of entries, bits 16-31 = quarters of a unit's time (128 cycles each) to sit out first (pacing).  Flags (the kernel tests them together after a unit):
 constexpr uint32_t RAILS_SWEEP_FLUSH = 0x100;         // the group's partial sums go to Y after this entry
 constexpr uint32_t RAILS_SWEEP_NO_TRIPS = 0x200;      // the entry has no trips (rows without nonzeros left: only the flush)
 constexpr uint32_t RAILS_SWEEP_LAST = 0x400;          // last entry of the step
@@ -43,7 +43,9 @@ struct rails_sweep_params {
     int ahead = 1;      // segments being filled at any time: step k asks for the rows of step k + ahead (NSEG - ahead are readable)
     int parts = 8;      // row ranges (XCDs)
     int phases = 4;     // workgroups per (part, column chunk)
-    int level = 1;      // level the waves of a workgroup step by step (0: every unit as late as its X rows allow)
+    int level = 2;      // 1: the waves of a workgroup run the same number of units in every step; 2: and the workgroups of a part's column
+                        // chunk keep pace (pauses); 0: every unit as late as its X rows allow
+    int level_slack = 32; // units of time a workgroup may be ahead of the slowest one of its chunk (level 2)
     int level_min_fill = 16; // a unit run early to level must consume at least this many nonzeros (of 4 x 16)
 };
 
