@@ -524,10 +524,17 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     }
     bool done = false;
     const bool vec2 = ((xc0 | yc0) & 1) == 0 && (ldg % 2 == 0);
-    // banded patterns at panel width: the sweep kernel (spmm_sweep.hip).  Auto: the window of columns of a row has to fit
-    // (phases - 1) blocks of 2816 rows (the planner decides exactly), and every XCD's part should hold a few blocks per phase.
-    if (A->variant == 7 || (A->variant == 0 && (nc == 128 || nc == 64) && A->n_ghost == 0 && A->window_rows > 0 &&
-                            A->window_rows + 256 <= (int64_t)(32 / (nc / 16) - 1) * 2816 && A->m >= (int64_t)8 * 4 * (32 / (nc / 16)) * 2816 / 4)) {
+    // banded patterns at panel width: the sweep kernel (spmm_sweep.hip).  Auto (all of it known without building the schedule, which takes
+    // a second per million rows): 64 to 256 columns in chunks of 16 that divide the 32 workgroups of an XCD; the window of columns of a
+    // row fits (phases - 1) blocks of 2816 rows (the planner decides exactly); every XCD's part holds a few blocks per phase; and an X
+    // row is staged by at most 8 workgroups per row of the part (phases x (1 + window / rows of a part): the launcher's own bound).
+    bool sweep_auto = false;
+    if (A->variant == 0 && nc >= 64 && nc <= 256 && nc % 16 == 0 && 32 % (nc / 16) == 0 && A->n_ghost == 0 && A->window_rows > 0) {
+        const int64_t phases = 32 / (nc / 16), part_rows = A->m / 8;
+        sweep_auto = A->window_rows + 256 <= (phases - 1) * 2816 && A->m >= 8 * phases * 2816 &&
+                     (double)phases * (double)(part_rows + A->window_rows + 1024) <= 8.0 * (double)part_rows;
+    }
+    if (A->variant == 7 || sweep_auto) {
         const bool al = ((xc0 | yc0) & 1) == 0 && X->ld % 2 == 0 && Y->ld % 2 == 0 && ldg % 2 == 0;
         RAILS_TRY(rails_spmm_sweep(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, al, A->variant == 7, &done));
         if (done) return RAILS_OK;

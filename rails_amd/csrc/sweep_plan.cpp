@@ -2,6 +2,8 @@
 #include "sweep_plan.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -327,10 +329,11 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                 plan.why = "columns of a row are not sorted";
                 return false;
             }
-    int64_t staged = 0;
-    std::vector<std::vector<GroupRun>> runs((size_t)P * W, std::vector<GroupRun>(G));
-    std::vector<int> pause;
-    for (int x = 0; x < prm.parts; ++x) {
+    // The parts are independent: each is planned by a thread of its own into a plan of its own, and the pieces are joined afterwards.
+    const std::vector<int64_t> part_row0 = plan.part_row0;
+    auto plan_part = [&](int x, rails_sweep_plan &plan, int64_t &staged) -> bool {
+        std::vector<std::vector<GroupRun>> runs((size_t)P * W, std::vector<GroupRun>(G));
+        std::vector<int> pause;
         Ctx c;
         c.prm = &prm;
         c.rowptr = rowptr;
@@ -355,7 +358,7 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
         plan.sweep0[x] = c.sweep0;
         plan.nsteps[x] = c.nsteps;
         staged += (int64_t)c.nsteps * SEG * P;
-        if (!schedule_part(c, runs, pause, plan.why)) return false;
+        if (!schedule_part(c, runs, pause, plan.why)) return false; // (this part)
         for (int ph = 0; ph < P; ++ph) {
             for (int w = 0; w < W; ++w) {
                 const int64_t prog = ((int64_t)x * P + ph) * W + w;
@@ -377,7 +380,7 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                             const uint8_t fl = gr[g].out.flags[up[g]++];
                             if (n + 1 > RAILS_SWEEP_CODES - 1) {
                                 plan.why = "more than 63 units of one wave in one step (step " + std::to_string(k) + " of " + std::to_string(c.nsteps) + ", part " + std::to_string(x) + ")";
-                                return false;
+                                return false; // (this part)
                             }
                             rec[1 + n++] = (uint32_t)(g * 8) | ((fl & 1) ? RAILS_SWEEP_FLUSH : 0u) | ((fl & 2) ? RAILS_SWEEP_NO_TRIPS : 0u);
                             if (!(fl & 2)) {
@@ -411,6 +414,54 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                 plan.trips += trip;
             }
         }
+            return true;
+    };
+    std::vector<rails_sweep_plan> piece(prm.parts);
+    std::vector<int64_t> piece_staged(prm.parts, 0);
+    std::vector<char> piece_ok(prm.parts, 0);
+    {
+        const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)prm.parts, (int64_t)std::thread::hardware_concurrency(), 8, plan.nnz / 200000 + 1}));
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            for (int x = next++; x < prm.parts; x = next++) {
+                rails_sweep_plan &q = piece[x];
+                q.part_row0 = part_row0;
+                q.sweep0.assign(prm.parts, 0);
+                q.nsteps.assign(prm.parts, 1);
+                q.hdr_off.assign(nprog, 0);
+                q.batch_off.assign(nprog, 0);
+                q.flush_off.assign(nprog, 0);
+                piece_ok[x] = plan_part(x, q, piece_staged[x]) ? 1 : 0;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+    }
+    int64_t staged = 0;
+    for (int x = 0; x < prm.parts; ++x) {
+        rails_sweep_plan &q = piece[x];
+        if (!piece_ok[x]) {
+            plan.why = q.why;
+            return false;
+        }
+        const int64_t codes0 = (int64_t)plan.codes.size(), batch0 = (int64_t)(plan.vals.size() / 256), flush0 = (int64_t)plan.flush_rows.size();
+        for (int64_t prog = (int64_t)x * P * W; prog < (int64_t)(x + 1) * P * W; ++prog) {
+            plan.hdr_off[prog] = codes0 + q.hdr_off[prog];
+            plan.batch_off[prog] = batch0 + q.batch_off[prog];
+            plan.flush_off[prog] = flush0 + q.flush_off[prog];
+        }
+        plan.sweep0[x] = q.sweep0[x];
+        plan.nsteps[x] = q.nsteps[x];
+        plan.codes.insert(plan.codes.end(), q.codes.begin(), q.codes.end());
+        plan.vals.insert(plan.vals.end(), q.vals.begin(), q.vals.end());
+        plan.offs.insert(plan.offs.end(), q.offs.begin(), q.offs.end());
+        plan.flush_rows.insert(plan.flush_rows.end(), q.flush_rows.begin(), q.flush_rows.end());
+        plan.trips += q.trips;
+        plan.max_units_per_step = std::max(plan.max_units_per_step, q.max_units_per_step);
+        staged += piece_staged[x];
+        q = rails_sweep_plan();
     }
     // spare batches at the very end: the kernel requests batches up to six ahead of the trips it runs
     plan.vals.resize(plan.vals.size() + 8 * 256, 0.0);

@@ -13,9 +13,9 @@ timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.er
 timeout -k 10 400 python bench.py --no-cpu --subspace 0 > $O/bench_direct.json 2> $O/bench_direct.err && cat $O/bench_direct.json &&
 timeout -k 10 400 python bench.py --no-cpu --pattern stencil27 > $O/bench_stencil27.json 2> $O/bench_stencil27.err && cat $O/bench_stencil27.json &&
 timeout -k 10 400 python bench.py --no-cpu --force-hooks > $O/bench_hooks.json 2> $O/bench_hooks.err && cat $O/bench_hooks.json &&
-bash scripts/gpu_profile.sh r01 &&
-bash scripts/gpu_profile.sh r01d --subspace 0 &&
-bash scripts/gpu_profile.sh r01s --pattern stencil27 &&
+bash scripts/gpu_profile.sh r02 &&
+bash scripts/gpu_profile.sh r02d --subspace 0 &&
+bash scripts/gpu_profile.sh r02s --pattern stencil27 &&
 bash scripts/gpu_kernels.sh > $O/gpu_kernels.log 2>&1 && tail -5 $O/gpu_kernels.log &&
 cd $R && RAILS_RUN_SUBSPACE=1 timeout -k 10 600 python scripts/run_configs.py > $O/configs_default.jsonl 2> $O/configs_default.err &&
 timeout -k 10 600 python scripts/run_configs.py c1 c2 c3 c3s c4slab > $O/configs_direct.jsonl 2> $O/configs_direct.err &&

@@ -44,7 +44,7 @@ def test_two_ranks_share_one_gpu():
 
 def test_bench_line_contract():
     """the one JSON line of `python bench.py` (N = 1, small sizes): every field the bench contract names, with sane values"""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rows-per-gpu", "60000", "--steps", "5", "--warmup", "3", "--spmm-reps", "2", "--cpu-rows", "8000"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rows-per-gpu", "60000", "--steps", "5", "--warmup", "3", "--spmm-reps", "2", "--cpu-trips", "2", "--cpu-warmup", "2", "--direct-steps", "3"]
     p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
