@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-trips", type=int, default=3, help="cpu_baseline: trips of the full-size CPU run that are timed")
     ap.add_argument("--cpu-warmup", type=int, default=5, help="cpu_baseline: trips of the full-size CPU run before the timed ones (at most --warmup)")
+    ap.add_argument("--busy-steps", type=int, default=8, help="timed trips of the extra run with the GPU-busy meter on (0: skip it)")
     ap.add_argument("--direct-steps", type=int, default=8, help="timed trips of the extra run on the direct back end (0: skip it)")
     ap.add_argument("--spmm-variant", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
@@ -294,13 +295,41 @@ def main():
     sb_counts = (int(_sm.value), int(_bs.value))
     hist = solver.history()
     log("[rank %d] host sections (s, whole solve incl. warm-up): %s" % (rank, json.dumps(solver.profile())))
+    median_trip_ms = None
     if len(stamps) > W + 2:
         dts = np.diff(np.array(stamps))[W:]
+        median_trip_ms = 1e3 * float(np.median(dts))
         log("[rank %d] timed trips: median %.2f ms, slowest %.2f ms (trip %d); library allocations inside the timed region: %d (at trips %s)" % (
             rank, 1e3 * float(np.median(dts)), 1e3 * float(dts.max()), W + 1 + int(dts.argmax()), allocs[-1] - allocs[W - 1],
             [i + 1 for i in range(W, len(allocs)) if allocs[i] != allocs[i - 1]]))
     log("[rank %d] counters: %s %s" % (rank, json.dumps(ctx.stats()), json.dumps(solver.backend_stats())))
     log("[rank %d] %d trips in %.3fs -> %.2f it/s; Lanczos estimates %.3e -> %.3e; V.N()=%d" % (rank, K, elapsed, its, hist[0], hist[-1], solver.k))
+
+    # ---- GPU-busy fraction: a short run of its own on the same back end with the library's busy meter on (a pair of events around every
+    # launch, a few microseconds each: not in the timed region above) -----------------------------------------------------------------
+    gpu_busy_frac = None
+    if args.busy_steps > 0:
+        Wb, Kb = min(W, 6), args.busy_steps
+        marks_b, busy_b = {}, {}
+        solver.set_option("max_trips", Wb + Kb)
+        ctx.set_meter(True)
+
+        def on_trip_busy(trip):
+            if trip == Wb or trip == Wb + Kb:
+                ctx.sync()
+                marks_b[trip] = time.perf_counter()
+                busy_b[trip] = ctx.stats().get("gpu_busy_ms", 0.0)
+
+        solver.set_trip_callback(on_trip_busy)
+        gc.disable()
+        try:
+            solver.solve(fetch=False)
+        finally:
+            gc.enable()
+        ctx.set_meter(False)
+        if Wb in marks_b and Wb + Kb in marks_b:
+            gpu_busy_frac = (busy_b[Wb + Kb] - busy_b[Wb]) * 1e-3 / (marks_b[Wb + Kb] - marks_b[Wb])
+            log("[rank %d] busy meter: %d trips in %.3fs, GPU at work %.1f ms -> %.3f" % (rank, Kb, marks_b[Wb + Kb] - marks_b[Wb], busy_b[Wb + Kb] - busy_b[Wb], gpu_busy_frac))
 
     # ---- the direct back end (device panels for V and AV: fused one-pass Lanczos kernel, block orthogonalisation on MFMA -- the north
     # star's literal path) on the same workload, a short timed run of its own: config.direct_backend_it_s ---------------------------
@@ -381,6 +410,10 @@ def main():
                        "global_rows": int(mg), "row_iterations_per_s": its * mg,
                        # the same workload on the direct back end (fused Lanczos kernel + block orthogonalisation), a short run of its own
                        "direct_backend_it_s": direct_its,
+                       # share of a trip during which the GPU is at work (the library's busy meter -- events around every launch -- over a short run
+                       # of its own); the rest is host work with the GPU idle
+                       "gpu_busy_frac": gpu_busy_frac,
+                       "median_trip_ms": median_trip_ms,
                        "host_projected_solve_routes": {"smith_or_adi": sb_counts[0], "bartels_stewart": sb_counts[1]}},
             "roofline": {"bound": "hbm", "kernel": spmm_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms,

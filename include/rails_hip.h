@@ -66,6 +66,10 @@ int rails_ctx_sync(rails_ctx *ctx);
 void *rails_ctx_stream(rails_ctx *ctx);
 /* call counters of this context as a JSON object (block vs column-wise orthogonalisations, SpMM kernel choice, ...) */
 int rails_ctx_stats(rails_ctx *ctx, char *buf, int cap);
+/* Busy meter: with on != 0 every kernel launch of this context is bracketed by a pair of events, read at the next synchronisation of
+ * its stream; "gpu_busy_ms" of rails_ctx_stats is the sum: the time the GPU was at work for this context.  Costs a few microseconds
+ * per launch: for measurement runs. */
+int rails_ctx_set_meter(rails_ctx *ctx, int on);
 
 /* Counter-based RNG: value = f(seed, stream id, GLOBAL row, column); every random
  * fill consumes one stream id.  Replaces StlWrapper::random's std::rand()-seeded

@@ -28,6 +28,7 @@ SIGNATURES = {
     "rails_ctx_destroy": (C.c_int, [_vp]),
     "rails_ctx_sync": (C.c_int, [_vp]),
     "rails_ctx_stream": (_vp, [_vp]),
+    "rails_ctx_set_meter": (C.c_int, [_vp, C.c_int]),
     "rails_ctx_stats": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "rails_ctx_set_seed": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "rails_ctx_rng_state": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

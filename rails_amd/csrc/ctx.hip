@@ -55,6 +55,7 @@ extern "C" int rails_ctx_create(int device, void *stream, rails_ctx **out)
         if (c->ev0) hipEventDestroy(c->ev0);
         if (c->ev1) hipEventDestroy(c->ev1);
         if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
+    for (hipEvent_t e : c->meter_events) hipEventDestroy(e);
         if (c->own_stream) hipStreamDestroy(c->stream);
         delete c;
         return RAILS_EHIP;
@@ -68,7 +69,7 @@ extern "C" int rails_ctx_destroy(rails_ctx *c)
 {
     if (!c) return RAILS_OK;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    rails_stream_sync(c);
     rails_lanczos_release(c);
     rails_rccl_release(c);
     for (auto &fp : c->free_panels) hipFree(fp.second);
@@ -79,6 +80,7 @@ extern "C" int rails_ctx_destroy(rails_ctx *c)
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
+    for (hipEvent_t e : c->meter_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return RAILS_OK;
@@ -87,7 +89,7 @@ extern "C" int rails_ctx_destroy(rails_ctx *c)
 extern "C" int rails_ctx_sync(rails_ctx *c)
 {
     RAILS_REQUIRE(c, "rails_ctx_sync: null context");
-    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    RAILS_HIP_CHECK(rails_stream_sync(c));
     return RAILS_OK;
 }
 
@@ -96,13 +98,26 @@ extern "C" int rails_ctx_stats(rails_ctx *c, char *buf, int cap)
     RAILS_REQUIRE(c && buf && cap > 0, "rails_ctx_stats: bad argument");
     int n = snprintf(buf, (size_t)cap,
                      "{\"orth_block\": %ld, \"orth_columnwise\": %ld, \"spmm_tiled\": %ld, \"spmm_sweep\": %ld, \"spmm_rowgather\": %ld, \"spmm_callback\": %ld, \"device_allocations\": %ld, \"allreduce\": %ld, "
-                     "\"lanczos\": %ld, \"lanczos_start\": %ld, \"orth_repair\": %ld}",
-                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_sweep, c->n_spmm_rowgather, c->n_spmm_callback, c->n_dev_alloc, c->n_allreduce, c->n_lanczos, c->n_lanczos_start, c->n_orth_repair);
+                     "\"lanczos\": %ld, \"lanczos_start\": %ld, \"orth_repair\": %ld, \"gpu_busy_ms\": %.3f}",
+                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_sweep, c->n_spmm_rowgather, c->n_spmm_callback, c->n_dev_alloc, c->n_allreduce, c->n_lanczos, c->n_lanczos_start, c->n_orth_repair, c->gpu_busy_ms);
     RAILS_REQUIRE(n > 0 && n < cap, "rails_ctx_stats: buffer too small");
     return RAILS_OK;
 }
 
 extern "C" void *rails_ctx_stream(rails_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int rails_ctx_set_meter(rails_ctx *c, int on)
+{
+    RAILS_REQUIRE(c, "rails_ctx_set_meter: null context");
+    hipSetDevice(c->device);
+    RAILS_HIP_CHECK(rails_stream_sync(c)); // what is pending is read (or, switching on, not bracketed: nothing to read)
+    if (on && c->meter_events.empty()) {
+        c->meter_events.resize(2 * RAILS_METER_PAIRS, nullptr);
+        for (hipEvent_t &e : c->meter_events) RAILS_HIP_CHECK(hipEventCreate(&e));
+    }
+    c->meter = on != 0;
+    return RAILS_OK;
+}
 
 extern "C" int rails_ctx_rng_state(rails_ctx *c, uint64_t *seed, uint64_t *next_stream)
 {
@@ -164,7 +179,7 @@ int rails_allreduce_dev(rails_ctx *c, double *dev, size_t n)
 static int grow(rails_ctx *c, double **p, size_t *have, size_t need, bool host)
 {
     if (need <= *have) return RAILS_OK;
-    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    RAILS_HIP_CHECK(rails_stream_sync(c));
     if (*p) {
         if (host)
             RAILS_HIP_CHECK(hipHostFree(*p));
@@ -256,7 +271,7 @@ extern "C" int rails_panel_create(rails_ctx *c, int64_t m_local, int capacity, r
         if (getenv("RAILS_TRACE_ALLOC")) fprintf(stderr, "rails alloc: panel %lld x %d (%zu bytes)\n", (long long)m_local, capacity, bytes);
         hipError_t e = hipMalloc((void **)&P->d, bytes);
         if (e != hipSuccess && !c->free_panels.empty()) { // give the cached buffers back and try again
-            hipStreamSynchronize(c->stream);
+            rails_stream_sync(c);
             for (auto &fp : c->free_panels) hipFree(fp.second);
             c->free_panels.clear();
             c->free_panel_bytes = 0;
@@ -285,7 +300,7 @@ extern "C" int rails_panel_destroy(rails_panel *P)
             c->free_panels.push_back(std::make_pair(bytes, P->d));
             c->free_panel_bytes += bytes;
         } else {
-            hipStreamSynchronize(c->stream);
+            rails_stream_sync(c);
             hipFree(P->d);
         }
     }
@@ -338,9 +353,9 @@ extern "C" int rails_panel_reserve(rails_ctx *c, rails_panel *P, int capacity)
     }
     RAILS_HIP_CHECK(hipMemsetAsync(nd, 0, bytes, c->stream));
     if (P->m > 0 && P->cap > 0)
-        hipLaunchKernelGGL(k_copy2d, dim3(grid_for(c, P->m * P->cap, 256)), dim3(256), 0, c->stream, P->d, P->ld, nd, nld,
+        RAILS_LAUNCH(k_copy2d, dim3(grid_for(c, P->m * P->cap, 256)), dim3(256), 0, c->stream, P->d, P->ld, nd, nld,
                            P->m, P->cap);
-    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    RAILS_HIP_CHECK(rails_stream_sync(c));
     RAILS_HIP_CHECK(hipFree(P->d));
     P->d = nd;
     P->ld = nld;
@@ -410,8 +425,8 @@ extern "C" int rails_panel_upload(rails_ctx *c, rails_panel *P, int c0, int nc, 
         RAILS_HIP_CHECK(hipMemcpy2DAsync(c->ws, (size_t)P->m * sizeof(double), host + (int64_t)j0 * ldh, (size_t)ldh * sizeof(double),
                                          (size_t)P->m * sizeof(double), n, hipMemcpyHostToDevice, c->stream));
         dim3 grid((unsigned)((P->m + 31) / 32), (unsigned)((n + 31) / 32));
-        hipLaunchKernelGGL(k_scatter_cm_to_panel, grid, dim3(256), 0, c->stream, c->ws, P->d + c0 + j0, P->ld, P->m, n);
-        RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        RAILS_LAUNCH(k_scatter_cm_to_panel, grid, dim3(256), 0, c->stream, c->ws, P->d + c0 + j0, P->ld, P->m, n);
+        RAILS_HIP_CHECK(rails_stream_sync(c));
     }
     RAILS_HIP_CHECK(hipGetLastError());
     return RAILS_OK;
@@ -429,10 +444,10 @@ extern "C" int rails_panel_download(rails_ctx *c, const rails_panel *P, int c0, 
     for (int j0 = 0; j0 < nc; j0 += chunk) {
         int n = nc - j0 < chunk ? nc - j0 : chunk;
         dim3 grid((unsigned)((P->m + 31) / 32), (unsigned)((n + 31) / 32));
-        hipLaunchKernelGGL(k_gather_panel_to_cm, grid, dim3(256), 0, c->stream, P->d + c0 + j0, P->ld, c->ws, P->m, n);
+        RAILS_LAUNCH(k_gather_panel_to_cm, grid, dim3(256), 0, c->stream, P->d + c0 + j0, P->ld, c->ws, P->m, n);
         RAILS_HIP_CHECK(hipMemcpy2DAsync(host + (int64_t)j0 * ldh, (size_t)ldh * sizeof(double), c->ws, (size_t)P->m * sizeof(double),
                                          (size_t)P->m * sizeof(double), n, hipMemcpyDeviceToHost, c->stream));
-        RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        RAILS_HIP_CHECK(rails_stream_sync(c));
     }
     RAILS_HIP_CHECK(hipGetLastError());
     return RAILS_OK;
@@ -497,7 +512,7 @@ extern "C" int rails_panel_fill(rails_ctx *c, rails_panel *P, int c0, int nc, do
     if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
     RAILS_TRY(check_window(P, c0, nc, "rails_panel_fill"));
     if (nc == 0 || P->m == 0) return RAILS_OK;
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(c, P->m * nc, 256)), dim3(256), 0, c->stream, P->d + c0, P->ld, P->m, nc, value);
+    RAILS_LAUNCH(k_fill, dim3(grid_for(c, P->m * nc, 256)), dim3(256), 0, c->stream, P->d + c0, P->ld, P->m, nc, value);
     RAILS_HIP_CHECK(hipGetLastError());
     return RAILS_OK;
 }
@@ -506,7 +521,7 @@ extern "C" int rails_panel_scale(rails_ctx *c, rails_panel *P, int c0, int nc, d
 {
     RAILS_TRY(check_window(P, c0, nc, "rails_panel_scale"));
     if (nc == 0 || P->m == 0) return RAILS_OK;
-    hipLaunchKernelGGL(k_scale, dim3(grid_for(c, P->m * nc, 256)), dim3(256), 0, c->stream, P->d + c0, P->ld, P->m, nc, s);
+    RAILS_LAUNCH(k_scale, dim3(grid_for(c, P->m * nc, 256)), dim3(256), 0, c->stream, P->d + c0, P->ld, P->m, nc, s);
     RAILS_HIP_CHECK(hipGetLastError());
     return RAILS_OK;
 }
@@ -521,7 +536,7 @@ extern "C" int rails_panel_copy(rails_ctx *c, const rails_panel *X, int xc0, int
         if (xc0 == yc0) return RAILS_OK;
         RAILS_REQUIRE(xc0 + nc <= yc0 || yc0 + nc <= xc0, "rails_panel_copy: overlapping windows of one panel");
     }
-    hipLaunchKernelGGL(k_copy2d, dim3(grid_for(c, X->m * nc, 256)), dim3(256), 0, c->stream, X->d + xc0, X->ld, Y->d + yc0,
+    RAILS_LAUNCH(k_copy2d, dim3(grid_for(c, X->m * nc, 256)), dim3(256), 0, c->stream, X->d + xc0, X->ld, Y->d + yc0,
                        Y->ld, X->m, nc);
     RAILS_HIP_CHECK(hipGetLastError());
     return RAILS_OK;
@@ -533,7 +548,7 @@ extern "C" int rails_panel_axpy(rails_ctx *c, double alpha, const rails_panel *X
     RAILS_TRY(check_window(Y, yc0, nc, "rails_panel_axpy(Y)"));
     RAILS_REQUIRE(X->m == Y->m, "rails_panel_axpy: row mismatch %lld vs %lld", (long long)X->m, (long long)Y->m);
     if (nc == 0 || X->m == 0) return RAILS_OK;
-    hipLaunchKernelGGL(k_axpy, dim3(grid_for(c, X->m * nc, 256)), dim3(256), 0, c->stream, alpha, X->d + xc0, X->ld,
+    RAILS_LAUNCH(k_axpy, dim3(grid_for(c, X->m * nc, 256)), dim3(256), 0, c->stream, alpha, X->d + xc0, X->ld,
                        Y->d + yc0, Y->ld, X->m, nc);
     RAILS_HIP_CHECK(hipGetLastError());
     return RAILS_OK;
@@ -545,7 +560,7 @@ extern "C" int rails_panel_random(rails_ctx *c, rails_panel *P, int c0, int nc)
     RAILS_TRY(check_window(P, c0, nc, "rails_panel_random"));
     uint64_t s = c->next_stream++;
     if (nc == 0 || P->m == 0) return RAILS_OK;
-    hipLaunchKernelGGL(k_random, dim3(grid_for(c, P->m * nc, 256)), dim3(256), 0, c->stream, P->d + c0, P->ld, P->m, nc,
+    RAILS_LAUNCH(k_random, dim3(grid_for(c, P->m * nc, 256)), dim3(256), 0, c->stream, P->d + c0, P->ld, P->m, nc,
                        c->seed, s, c->row0);
     RAILS_HIP_CHECK(hipGetLastError());
     return RAILS_OK;

@@ -213,7 +213,7 @@ void launch_gram(rails_ctx *c, const double *X, int ldx, int a, const double *Y,
                  int64_t nslab, double *partial)
 {
     int ngi = (a + 16 * TI - 1) / (16 * TI), ngj = (b + 16 * TJ - 1) / (16 * TJ);
-    hipLaunchKernelGGL((k_gram<TI, TJ>), dim3((unsigned)nslab, (unsigned)(ngi * ngj)), dim3(256), 0, c->stream, X, ldx, a, Y, ldy, b,
+    RAILS_LAUNCH((k_gram<TI, TJ>), dim3((unsigned)nslab, (unsigned)(ngi * ngj)), dim3(256), 0, c->stream, X, ldx, a, Y, ldy, b,
                        m, rps, ngj, partial);
 }
 
@@ -296,7 +296,7 @@ void launch_pg(rails_ctx *c, double alpha, const double *X, int ldx, int k, cons
                int ldy, int64_t m, int vec_ok)
 {
     int64_t grid = (m + 63) / 64;
-    hipLaunchKernelGGL((k_panel_gemm<TR, KC>), dim3((unsigned)grid), dim3(256), 0, c->stream, alpha, X, ldx, k, C, r, beta, Y,
+    RAILS_LAUNCH((k_panel_gemm<TR, KC>), dim3((unsigned)grid), dim3(256), 0, c->stream, alpha, X, ldx, k, C, r, beta, Y,
                        ldy, m, vec_ok);
 }
 
@@ -332,7 +332,7 @@ int rails_gram_dev(rails_ctx *c, const double *X, int ldx, const double *Y, int 
             }
             const dim3 grid((unsigned)nslab, (unsigned)(((ntiles + best - 1) / best + 3) / 4));
 #define RAILS_GRAM_COLS_CASE(TI, TJ)                                                                                                     \
-    hipLaunchKernelGGL((k_gram_cols<TI, TJ>), grid, dim3(256), 0, c->stream, X, ldx, a, Y, ldy, b, m, rps, c->ws)
+    RAILS_LAUNCH((k_gram_cols<TI, TJ>), grid, dim3(256), 0, c->stream, X, ldx, a, Y, ldy, b, m, rps, c->ws)
             if (b <= 16) {
                 if (best == 4)
                     RAILS_GRAM_COLS_CASE(4, 1);
@@ -365,7 +365,7 @@ int rails_gram_dev(rails_ctx *c, const double *X, int ldx, const double *Y, int 
         launch_gram<2, 4>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
     else
         launch_gram<2, 4>(c, X, ldx, a, Y, ldy, b, m, rps, nslab, c->ws);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, c->stream, c->ws, nslab, (int64_t)n, C_dev);
+    RAILS_LAUNCH(k_reduce_partials, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, c->stream, c->ws, nslab, (int64_t)n, C_dev);
     RAILS_HIP_CHECK(hipGetLastError());
     return RAILS_OK;
 }
@@ -390,7 +390,7 @@ extern "C" int rails_gram(rails_ctx *c, const rails_panel *X, int xc0, int a, co
         RAILS_HIP_CHECK(hipMemsetAsync(c->small, 0, n * sizeof(double), c->stream));
     RAILS_TRY(rails_allreduce_dev(c, c->small, n));
     RAILS_HIP_CHECK(hipMemcpyAsync(c->pinned, c->small, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    RAILS_HIP_CHECK(rails_stream_sync(c));
     for (int j = 0; j < b; ++j) memcpy(C_host + (size_t)j * ldc, c->pinned + (size_t)j * a, sizeof(double) * a);
     return RAILS_OK;
 }

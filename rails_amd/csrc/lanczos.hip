@@ -430,7 +430,7 @@ void launch_pass_u(rails_ctx *c, const LzArgs &a, int *nblocks_io, bool size_onl
         *nblocks_io = c->num_cu * occ;
         return;
     }
-    hipLaunchKernelGGL((k_lanczos_pass<NCH, U>), dim3(*nblocks_io), dim3(256), 0, c->stream, a);
+    RAILS_LAUNCH((k_lanczos_pass<NCH, U>), dim3(*nblocks_io), dim3(256), 0, c->stream, a);
 }
 
 int lz_unroll()
@@ -475,7 +475,7 @@ static int lz_run(rails_ctx *c, const rails_panel *AV, int avc0, const rails_pan
     // Lanczos vectors
     size_t qbytes = (size_t)(L + 2) * (size_t)std::max<int64_t>(mpad, 64) * sizeof(double);
     if (qbytes > S.qc_bytes) {
-        RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        RAILS_HIP_CHECK(rails_stream_sync(c));
         if (S.Qc) RAILS_HIP_CHECK(hipFree(S.Qc));
         S.Qc = nullptr;
         S.qc_bytes = 0;
@@ -503,7 +503,7 @@ static int lz_run(rails_ctx *c, const rails_panel *AV, int avc0, const rails_pan
     // small device block: T | coef | sums | state(8) | alphas(L+2) | betas(L+2)
     size_t nsmall = (size_t)k * k + ncoef + ncoef + 8 + 2 * (size_t)(L + 2);
     if (nsmall * sizeof(double) > S.small_bytes) {
-        RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        RAILS_HIP_CHECK(rails_stream_sync(c));
         if (S.small) RAILS_HIP_CHECK(hipFree(S.small));
         S.small = nullptr;
         RAILS_HIP_CHECK(hipMalloc((void **)&S.small, nsmall * sizeof(double) * 2));
@@ -527,7 +527,7 @@ static int lz_run(rails_ctx *c, const rails_panel *AV, int avc0, const rails_pan
     {
         uint64_t stream = c->next_stream++;
         int grid = (int)std::min<int64_t>((S.mpad + 255) / 256, (int64_t)c->num_cu * 8);
-        hipLaunchKernelGGL(k_lz_random, dim3(grid), dim3(256), 0, c->stream, S.Qc, m, S.mpad, c->seed, stream, c->row0);
+        RAILS_LAUNCH(k_lz_random, dim3(grid), dim3(256), 0, c->stream, S.Qc, m, S.mpad, c->seed, stream, c->row0);
     }
     LzArgs a;
     a.AV = AV->d + avc0;
@@ -550,16 +550,16 @@ static int lz_run(rails_ctx *c, const rails_panel *AV, int avc0, const rails_pan
     for (int step = -1; step < (only_start ? 0 : L); ++step) {
         a.step = step;
         launch_pass(c, a, nch, &nblocks, false);
-        hipLaunchKernelGGL(k_lz_reduce, dim3((ncoef + 63) / 64), dim3(1024), 0, c->stream, c->ws, nblocks, ncoef, dsums);
+        RAILS_LAUNCH(k_lz_reduce, dim3((ncoef + 63) / 64), dim3(1024), 0, c->stream, c->ws, nblocks, ncoef, dsums);
         RAILS_TRY(rails_allreduce_dev(c, dsums, (size_t)ncoef));
         if (only_start) break;
-        hipLaunchKernelGGL(k_lz_small, dim3(1), dim3(1024), 0, c->stream, dsums, dT, k, p, step, dcoef, dstate, dalpha, dbeta);
+        RAILS_LAUNCH(k_lz_small, dim3(1), dim3(1024), 0, c->stream, dsums, dT, k, p, step, dcoef, dstate, dalpha, dbeta);
     }
     RAILS_HIP_CHECK(hipGetLastError());
     if (only_start) { // [AV^T q0 | MV^T q0 | B^T q0 | q0^T q0], q0 kept (raw) as Lanczos vector 0
         RAILS_TRY(rails_pinned_reserve(c, (size_t)ncoef * sizeof(double)));
         RAILS_HIP_CHECK(hipMemcpyAsync(c->pinned, dsums, (size_t)ncoef * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        RAILS_HIP_CHECK(rails_stream_sync(c));
         memcpy(start_sums_host, c->pinned, (size_t)ncoef * sizeof(double));
         S.steps = 1;
         c->n_lanczos_start++;
@@ -568,7 +568,7 @@ static int lz_run(rails_ctx *c, const rails_panel *AV, int avc0, const rails_pan
     // read back state, alphas, betas (contiguous)
     size_t nback = 8 + 2 * (size_t)(L + 2);
     RAILS_HIP_CHECK(hipMemcpyAsync(c->pinned, dstate, nback * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    RAILS_HIP_CHECK(rails_stream_sync(c));
     const double *hstate = c->pinned, *halpha = c->pinned + 8, *hbeta = halpha + (L + 2);
     const bool broke = hstate[3] != 0.0;
     int steps = broke ? (int)hstate[4] : L;
@@ -623,11 +623,11 @@ extern "C" int rails_lanczos_vectors(rails_ctx *c, const double *S_host, int lds
     RAILS_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     for (int j0 = 0; j0 < w; j0 += 16) {
         int wc = std::min(16, w - j0);
-        hipLaunchKernelGGL(k_lz_vectors, dim3((unsigned)((S.m + 255) / 256)), dim3(256), (size_t)steps * 16 * sizeof(double), c->stream,
+        RAILS_LAUNCH(k_lz_vectors, dim3((unsigned)((S.m + 255) / 256)), dim3(256), (size_t)steps * 16 * sizeof(double), c->stream,
                            S.Qc, S.mpad, S.m, steps, c->small + (size_t)j0 * steps, steps, wc, Out->d + oc0 + j0, Out->ld);
     }
     RAILS_HIP_CHECK(hipGetLastError());
-    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    RAILS_HIP_CHECK(rails_stream_sync(c));
     return RAILS_OK;
 }
 
@@ -635,7 +635,7 @@ extern "C" int rails_lanczos_release(rails_ctx *c)
 {
     if (!c || !c->lz) return RAILS_OK;
     rails_lanczos_state *S = static_cast<rails_lanczos_state *>(c->lz);
-    hipStreamSynchronize(c->stream);
+    rails_stream_sync(c);
     if (S->Qc) hipFree(S->Qc);
     if (S->small) hipFree(S->small);
     delete S;

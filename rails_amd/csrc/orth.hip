@@ -24,7 +24,7 @@ int sync_small_to_host(rails_ctx *c, size_t n, std::vector<double> &out)
 {
     RAILS_TRY(rails_pinned_reserve(c, n * sizeof(double)));
     RAILS_HIP_CHECK(hipMemcpyAsync(c->pinned, c->small, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    RAILS_HIP_CHECK(rails_stream_sync(c));
     out.assign(c->pinned, c->pinned + n);
     return RAILS_OK;
 }
@@ -34,7 +34,7 @@ int upload_small(rails_ctx *c, const std::vector<double> &in, double *dst)
     RAILS_TRY(rails_pinned_begin_write(c, in.size() * sizeof(double)));
     memcpy(c->pinned, in.data(), in.size() * sizeof(double));
     RAILS_HIP_CHECK(hipMemcpyAsync(dst, c->pinned, in.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    RAILS_HIP_CHECK(rails_stream_sync(c));
     return RAILS_OK;
 }
 

@@ -76,10 +76,46 @@ struct rails_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_h2d = nullptr; // recorded after an asynchronous upload out of `pinned`; waited for before the host writes there again
     bool h2d_pending = false;
+    // busy meter (rails_ctx_set_meter): a pair of events around every launch; the pairs are read at the next synchronisation of the stream
+    bool meter = false;
+    std::vector<hipEvent_t> meter_events; // 2 x RAILS_METER_PAIRS
+    int meter_open = 0;                   // pairs recorded since the last synchronisation
+    long meter_missed = 0;                // launches that found no free pair
+    double gpu_busy_ms = 0.0;
     // counters (rails_ctx_stats)
     void *lz = nullptr; // rails_lanczos_state (lanczos.hip), released by rails_lanczos_release
     long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_sweep = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_dev_alloc = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0;
 };
+
+// the busy meter (see rails_ctx): RAILS_LAUNCH brackets a launch, rails_stream_sync reads what has been bracketed since the last one
+constexpr int RAILS_METER_PAIRS = 512;
+inline bool rails_meter_before(rails_ctx *c)
+{
+    if (!c->meter) return false;
+    if (c->meter_open >= RAILS_METER_PAIRS) {
+        c->meter_missed++;
+        return false;
+    }
+    hipEventRecord(c->meter_events[2 * c->meter_open], c->stream);
+    return true;
+}
+inline void rails_meter_after(rails_ctx *c) { hipEventRecord(c->meter_events[2 * c->meter_open++ + 1], c->stream); }
+inline hipError_t rails_stream_sync(rails_ctx *c)
+{
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    for (int i = 0; i < c->meter_open; ++i) {
+        float ms = 0.0f;
+        if (e == hipSuccess && hipEventElapsedTime(&ms, c->meter_events[2 * i], c->meter_events[2 * i + 1]) == hipSuccess) c->gpu_busy_ms += ms;
+    }
+    c->meter_open = 0;
+    return e;
+}
+#define RAILS_LAUNCH(...)                                                                                                                  \
+    do {                                                                                                                                   \
+        const bool rails_metered = rails_meter_before(c);                                                                                  \
+        hipLaunchKernelGGL(__VA_ARGS__);                                                                                                   \
+        if (rails_metered) rails_meter_after(c);                                                                                           \
+    } while (0)
 
 struct rails_panel {
     rails_ctx *ctx = nullptr;

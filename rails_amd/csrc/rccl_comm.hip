@@ -113,7 +113,7 @@ extern "C" int rails_ctx_set_rccl(rails_ctx *c, void *nccl_comm)
 {
     RAILS_REQUIRE(c, "rails_ctx_set_rccl: null context");
     if (c->rccl && c->own_rccl) {
-        RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        RAILS_HIP_CHECK(rails_stream_sync(c));
         g_rccl.CommDestroy((ncclComm_t)c->rccl);
     }
     c->rccl = nullptr;

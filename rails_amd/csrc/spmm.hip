@@ -133,7 +133,7 @@ int launch_rg(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const 
         grid = bpx * 8;
     }
     RAILS_REQUIRE(grid <= 0x7fffffffLL, "rails_spmm: grid too large");
-    hipLaunchKernelGGL((k_spmm_rowgather<LPR, VEC, RPG>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col,
+    RAILS_LAUNCH((k_spmm_rowgather<LPR, VEC, RPG>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col,
                        A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx);
     return RAILS_OK;
 }
@@ -239,7 +239,7 @@ int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, con
     const int64_t grid = bpx * 8 * nchunks;
     RAILS_REQUIRE(grid <= 0x7fffffffLL, "rails_spmm: grid too large");
     const int lds_cap = 2048; // nonzeros of one block staged in LDS (24 KiB); longer runs read (col, val) from global memory
-    hipLaunchKernelGGL((k_spmm_rowgather_cc<LPR, RPG>), dim3((unsigned)grid), dim3(256), (size_t)lds_cap * 12, c->stream, A->m, A->rowptr,
+    RAILS_LAUNCH((k_spmm_rowgather_cc<LPR, RPG>), dim3((unsigned)grid), dim3(256), (size_t)lds_cap * 12, c->stream, A->m, A->rowptr,
                        A->col, A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx, lds_cap, y_vec ? 1 : 0);
     return RAILS_OK;
 }
@@ -348,7 +348,7 @@ extern "C" int rails_csr_create(rails_ctx *c, int64_t m_local, int64_t n_cols_ex
     hipError_t ce = hipMemcpyAsync(A->rowptr, rowptr, (size_t)(m_local + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
     if (ce == hipSuccess && nnz) ce = hipMemcpyAsync(A->col, col, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
     if (ce == hipSuccess && nnz) ce = hipMemcpyAsync(A->val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, c->stream);
-    if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
+    if (ce == hipSuccess) ce = rails_stream_sync(c);
     if (ce != hipSuccess) { // the half-made operator is released, not leaked
         rails_set_error("rails_csr_create: upload failed: %s", hipGetErrorString(ce));
         rails_csr_destroy(A);
@@ -437,7 +437,7 @@ extern "C" int rails_csr_set_halo(rails_csr *A, int64_t n_send, const int64_t *s
         RAILS_REQUIRE(send_rows[i] >= 0 && send_rows[i] < A->m, "rails_csr_set_halo: send row %lld out of range", (long long)send_rows[i]);
     rails_ctx *c = A->ctx;
     if (A->send_rows) {
-        RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        RAILS_HIP_CHECK(rails_stream_sync(c));
         RAILS_HIP_CHECK(hipFree(A->send_rows));
         A->send_rows = nullptr;
     }
@@ -491,14 +491,14 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         size_t sbytes = (size_t)(A->n_send ? A->n_send : 1) * nc * sizeof(double);
         size_t gbytes = (size_t)(A->n_ghost ? A->n_ghost : 1) * nc * sizeof(double);
         if (sbytes > A->send_cap) {
-            RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            RAILS_HIP_CHECK(rails_stream_sync(c));
             if (A->send_buf) RAILS_HIP_CHECK(hipFree(A->send_buf));
             A->send_buf = nullptr;
             RAILS_HIP_CHECK(hipMalloc((void **)&A->send_buf, sbytes));
             A->send_cap = sbytes;
         }
         if (gbytes > A->ext_cap) {
-            RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            RAILS_HIP_CHECK(rails_stream_sync(c));
             if (A->ext) RAILS_HIP_CHECK(hipFree(A->ext));
             A->ext = nullptr;
             RAILS_HIP_CHECK(hipMalloc((void **)&A->ext, gbytes));
@@ -507,7 +507,7 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         if (A->n_send) {
             int64_t total = A->n_send * nc;
             int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)c->num_cu * 8);
-            hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, c->stream, A->send_rows, A->n_send, Xp, X->ld, nc, A->send_buf);
+            RAILS_LAUNCH(k_pack_rows, dim3(grid), dim3(256), 0, c->stream, A->send_rows, A->n_send, Xp, X->ld, nc, A->send_buf);
         }
         if (A->halo) {
             int rc = A->halo(A->halo_user, A->send_buf, A->ext, nc, (void *)c->stream);
@@ -1271,7 +1271,7 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
 #define RAILS_LAUNCH_REG_NS(KCV, NNZV, NLV, V2V, NSV)                                                                                 \
     do {                                                                                                                               \
         RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled_reg<KCV, NNZV, NLV, V2V, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg)); \
-        hipLaunchKernelGGL((k_spmm_tiled_reg<KCV, NNZV, NLV, V2V, NSV>), dim3((unsigned)grid), dim3(256), lds_reg, c->stream, RAILS_REG_ARGS); \
+        RAILS_LAUNCH((k_spmm_tiled_reg<KCV, NNZV, NLV, V2V, NSV>), dim3((unsigned)grid), dim3(256), lds_reg, c->stream, RAILS_REG_ARGS); \
     } while (0)
 #define RAILS_LAUNCH_REG(KCV, NNZV, NLV, V2V)                                                                                         \
     do {                                                                                                                               \
@@ -1320,7 +1320,7 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
 #define RAILS_LAUNCH_PIPE(KCV, NLV)                                                                                                    \
     do {                                                                                                                               \
         RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled_pipe<KCV, NLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)); \
-        hipLaunchKernelGGL((k_spmm_tiled_pipe<KCV, NLV>), dim3((unsigned)grid), dim3(256), lds_pipe, c->stream, RAILS_TILED_ARGS);  \
+        RAILS_LAUNCH((k_spmm_tiled_pipe<KCV, NLV>), dim3((unsigned)grid), dim3(256), lds_pipe, c->stream, RAILS_TILED_ARGS);  \
     } while (0)
     if (pipe) {
         if (KC == 8) {
@@ -1332,10 +1332,10 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
         }
     } else if (KC == 8) {
         RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_spmm_tiled<8>), dim3((unsigned)grid), dim3(256), lds, c->stream, RAILS_TILED_ARGS);
+        RAILS_LAUNCH((k_spmm_tiled<8>), dim3((unsigned)grid), dim3(256), lds, c->stream, RAILS_TILED_ARGS);
     } else {
         RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_spmm_tiled<16>), dim3((unsigned)grid), dim3(256), lds, c->stream, RAILS_TILED_ARGS);
+        RAILS_LAUNCH((k_spmm_tiled<16>), dim3((unsigned)grid), dim3(256), lds, c->stream, RAILS_TILED_ARGS);
     }
 #undef RAILS_LAUNCH_PIPE
 #undef RAILS_TILED_ARGS

@@ -225,7 +225,7 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
             RAILS_TRY(up(c, &d->vals, d->host.vals));
             RAILS_TRY(up(c, &d->offs, d->host.offs));
             RAILS_TRY(up(c, &d->flush_rows, d->host.flush_rows));
-            RAILS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            RAILS_HIP_CHECK(rails_stream_sync(c));
             std::vector<double>().swap(d->host.vals);
             std::vector<uint16_t>().swap(d->host.offs);
             std::vector<uint32_t>().swap(d->host.codes);
@@ -253,7 +253,7 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
     static const int layout = getenv("RAILS_SWEEP_LAYOUT") ? atoi(getenv("RAILS_SWEEP_LAYOUT")) : 0;
     a.layout = layout;
 #define RAILS_SWEEP_LAUNCH(K)                                                                                                                     \
-    hipLaunchKernelGGL((K<SWEEP_W, SWEEP_G>), dim3(256), dim3(SWEEP_W * 64), 0, c->stream, a, d->part_row0, d->sweep0, d->nsteps, d->hdr_off, \
+    RAILS_LAUNCH((K<SWEEP_W, SWEEP_G>), dim3(256), dim3(SWEEP_W * 64), 0, c->stream, a, d->part_row0, d->sweep0, d->nsteps, d->hdr_off, \
                        d->batch_off, d->flush_off, d->codes, d->vals, d->offs, d->flush_rows, X, Xg, Y)
     switch ((ablate >> 4) & 15) {
     case 1: RAILS_SWEEP_LAUNCH(k_spmm_sweep_noread); break;

@@ -90,6 +90,10 @@ class Context:
         check(self.lib.rails_ctx_stats(self.h, buf, 1024), "rails_ctx_stats")
         return json.loads(buf.value.decode())
 
+    def set_meter(self, on=True):
+        """device-busy meter: stats()["gpu_busy_ms"] adds up the time the GPU worked for this context"""
+        check(self.lib.rails_ctx_set_meter(self.h, 1 if on else 0), "rails_ctx_set_meter")
+
     def timer_start(self):
         check(self.lib.rails_timer_start(self.h), "rails_timer_start")
 
