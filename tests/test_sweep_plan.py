@@ -95,3 +95,17 @@ def test_patterns_that_do_not_fit_are_refused():
     rowptr = np.array([0, 2], dtype=np.int64)
     with pytest.raises(RailsError, match="not sorted"):
         SweepPlan(rowptr, np.array([0, 0], np.int32)[::-1] + np.array([1, 0], np.int32), np.ones(2), ncols=4, params=(1, 2, 8, 5, 1, 2))
+
+
+def test_compiler_stays_out_of_the_assembly_registers():
+    """spmm_sweep.hip: the unit loop's inline assembly owns v24-v255; `amdgpu_num_vgpr(24)` keeps the compiler below them only while its
+    own values fit, so the generated code is checked (compile only: hipcc cross-compiles gfx950 without a GPU)."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "check_sweep_regs.py")
+    spec = importlib.util.spec_from_file_location("check_sweep_regs", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernels, bad = mod.check()
+    assert kernels >= 2 and not bad, bad[:5]
