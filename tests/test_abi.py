@@ -200,6 +200,66 @@ def test_host_sb03md_smith_route_is_verified_and_falls_back():
         assert np.linalg.norm(X - Xref) <= 1e-8 * np.linalg.norm(Xref)  # conditioning of these problems, same algorithm on both sides
 
 
+def test_host_sb03md_at_the_c4_size():
+    """The projected equation at BASELINE configs[3]'s size (Restart size 256, B m x 32): V'AV of a nonsymmetric 27-point stencil operator
+    on a 256-dimensional block Krylov space, right-hand side -(V'B)(V'B)' of rank 32.  Bartels-Stewart costs 21 ms there
+    (profiles/r01_host_lyap.txt); the factored ADI route has to take it (route counters, as bench.py reports them), verified against
+    scipy's Bartels-Stewart.  The symmetric stencil of C4 itself takes the eigen-decomposition path: checked beside it."""
+    import time
+
+    import scipy.linalg as sl
+    import scipy.sparse as sp
+
+    import rails_amd
+    from rails_amd import problems as P
+
+    lib = rails_amd.load()
+    dp = C.POINTER(C.c_double)
+
+    def counts():
+        a, b = C.c_long(0), C.c_long(0)
+        lib.rails_sb03md_counts(C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def projected(random_values):
+        rowptr, col, val = P.stencil27(24, 24, 12, random_values=random_values, seed=5)
+        m = rowptr.size - 1
+        A = sp.csr_matrix((val, col, rowptr), shape=(m, m))
+        V = np.linalg.qr(P.rhs(m, 32, seed=9))[0]
+        blocks = [V]
+        while sum(b.shape[1] for b in blocks) < 256:  # block Krylov space, orthonormalised block by block (twice)
+            W = A @ blocks[-1]
+            Q = np.hstack(blocks)
+            W -= Q @ (Q.T @ W)
+            W -= Q @ (Q.T @ W)
+            blocks.append(np.linalg.qr(W)[0])
+        V = np.hstack(blocks)[:, :256]
+        Bv = V.T @ P.rhs(m, 32, seed=9)
+        return V.T @ (A @ V), -(Bv @ Bv.T)
+
+    for random_values, want_route in ((True, "adi"), (False, "symmetric")):
+        M, Cm = projected(random_values)
+        n = M.shape[0]
+        assert n == 256
+        lib.rails_sb03md_set_pause(0)
+        s0, b0 = counts()
+        Ap, X = np.asfortranarray(M.copy()), np.asfortranarray(Cm.copy())
+        scale, info = C.c_double(0), C.c_int(0)
+        t = time.perf_counter()
+        lib.rails_sb03md(b"C", b"X", b"N", b"T", n, Ap.ctypes.data_as(dp), n, X.ctypes.data_as(dp), n, C.byref(scale), C.byref(info))
+        dt = time.perf_counter() - t
+        s1, b1 = counts()
+        assert info.value == 0 and scale.value == 1.0
+        if want_route == "adi":
+            assert (s1, b1) == (s0 + 1, b0), "the nonsymmetric n = 256 projection fell back to Bartels-Stewart"
+        else:
+            assert (s1, b1) == (s0, b0 + 1) or (s1, b1) == (s0, b0)  # eigen-decomposition path (counted with the direct solves, if at all)
+        Xref = sl.solve_continuous_lyapunov(M, Cm)
+        assert np.linalg.norm(X - Xref) <= 1e-10 * np.linalg.norm(Xref)
+        assert np.linalg.norm(M @ X + X @ M.T - Cm) <= 1e-13 * (2 * np.linalg.norm(M) * np.linalg.norm(X) + np.linalg.norm(Cm))
+        print("n = 256, %s stencil: %s route, %.1f ms" % ("random" if random_values else "fixed", want_route, 1e3 * dt))
+
+
 @pytest.mark.parametrize("loops", [0, 1])
 def test_host_dtrsm_all_forms(loops, monkeypatch):
     """rails_dtrsm (the six triangular solves of the generalized projected solve): BLAS path and the loop fallback, every
