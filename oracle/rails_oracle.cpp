@@ -1033,6 +1033,10 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
                             }
                             if (code & 0x100) {
                                 const int64_t row0 = flush_rows[flush_off[prog] + fl++];
+                                if ((int64_t)(code >> 12) * 16 + part_row0[x] != row0) { // the kernel takes the rows from the entry
+#pragma omp atomic write
+                                    rc = -5;
+                                }
                                 for (int s = 0; s < SLOTS; ++s) {
                                     const int64_t row = row0 + s;
                                     double *a = &acc[((size_t)g * SLOTS + s) * 16];

@@ -254,7 +254,7 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
     a.layout = layout;
 #define RAILS_SWEEP_LAUNCH(K)                                                                                                                     \
     RAILS_LAUNCH((K<SWEEP_W, SWEEP_G>), dim3(256), dim3(SWEEP_W * 64), 0, c->stream, a, d->part_row0, d->sweep0, d->nsteps, d->hdr_off, \
-                       d->batch_off, d->flush_off, d->codes, d->vals, d->offs, d->flush_rows, X, Xg, Y)
+                       d->batch_off, d->codes, d->vals, d->offs, X, Xg, Y)
     switch ((ablate >> 4) & 15) {
     case 1: RAILS_SWEEP_LAUNCH(k_spmm_sweep_noread); break;
     case 2: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nofma); break;

@@ -402,7 +402,16 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                                 }
                                 ++tp[g];
                             }
-                            if (fl & 1) plan.flush_rows.push_back(gr[g].out.flush[fp[g]++]);
+                            if (fl & 1) {
+                                // the rows the flush writes: sixteen from this one on, as a multiple of 16 from the part's first row in the entry
+                                const int64_t row = gr[g].out.flush[fp[g]++], rel = (row - c.r0) / 16;
+                                if ((row - c.r0) % 16 || rel >= (int64_t)1 << 20) {
+                                    plan.why = "a part has more rows than a record entry can name (16M)";
+                                    return false; // (this part)
+                                }
+                                rec[n] |= (uint32_t)rel << RAILS_SWEEP_ROW_SHIFT;
+                                plan.flush_rows.push_back((int32_t)row);
+                            }
                         }
                     // what the kernel branches on after a unit: anything but "go on with the next entry"
                     rec[0] = (uint32_t)n | ((uint32_t)pause[(size_t)ph * c.nsteps + k] << 16);

@@ -34,6 +34,7 @@ constexpr uint32_t RAILS_SWEEP_FLUSH = 0x100;         // the group's partial sum
 constexpr uint32_t RAILS_SWEEP_NO_TRIPS = 0x200;      // the entry has no trips (rows without nonzeros left: only the flush)
 constexpr uint32_t RAILS_SWEEP_LAST = 0x400;          // last entry of the step
 constexpr uint32_t RAILS_SWEEP_NEXT_NO_TRIPS = 0x800; // the next entry has no trips (in the header: the first entry)
+constexpr int RAILS_SWEEP_ROW_SHIFT = 12;             // entries with FLUSH: bits 12-31 = (first row of the flush - first row of the part) / 16
 
 struct rails_sweep_params {
     int waves = 8;      // W: waves per workgroup
