@@ -237,10 +237,17 @@ def main():
     achieved = alg_bytes / (spmm_ms * 1e-3) / 1e9
     del X, Y
     traffic = None
+    traffic_stale = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("%s:%s" % (spmm_kernel, args.pattern))
+            tj = json.load(open(tfile))
+            traffic = tj.get("%s:%s" % (spmm_kernel, args.pattern))
+            # the PMC passes behind that number ran the kernel at this average duration: a different one now means the kernel has changed
+            # since (the committed number is then about another build)
+            then_us = tj.get("%s:%s:kernel_us" % (spmm_kernel, args.pattern))
+            if traffic is not None and then_us:
+                traffic_stale = bool(abs(spmm_ms * 1e3 / then_us - 1.0) > 0.15)
         except Exception:
             traffic = None
     log("[rank %d] SpMM %s k=%d: %.3f ms, %.1f GB/s algorithmic (%.1f%% of %.0f GB/s)" % (rank, spmm_kernel, kk, spmm_ms, achieved,
@@ -416,7 +423,7 @@ def main():
                        "median_trip_ms": median_trip_ms,
                        "host_projected_solve_routes": {"smith_or_adi": sb_counts[0], "bartels_stewart": sb_counts[1]}},
             "roofline": {"bound": "hbm", "kernel": spmm_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms,
                          "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, corrected as profiles/README.md says)" if traffic else None,
                          "schedule": sweep_stats},
             "cpu_baseline": cpu,

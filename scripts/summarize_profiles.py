@@ -85,6 +85,14 @@ def main():
                 best[key] = (n_here, (2 * sum(fa2) / len(fa2) + sum(wa2) / len(wa2)) * 1024)
     lines.append("")
     traffic = {k: v[1] for k, v in best.items()}
+    # the kernel's average duration in the stats pass of the same build: bench.py compares it with what it measures live and says so in
+    # `roofline.traffic_stale` when the kernel has changed since these passes were made
+    if stats:
+        for key in list(traffic):
+            kname = key.split(":")[0]
+            durs = [(int(r["Calls"]), float(r["AverageNs"]) / 1e3) for r in rows if short(r["Name"]).split("<")[0] == kname]
+            if durs:
+                traffic[key + ":kernel_us"] = max(durs)[1]
     json.dump(traffic, open(os.path.join(dst, "traffic_%s_%s.json" % (tag, pattern)), "w"), indent=1)
     # merge into profiles/traffic.json (what bench.py reads)
     tj = os.path.join(dst, "traffic.json")
