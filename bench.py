@@ -180,6 +180,13 @@ def main():
             except Exception as e:  # fall back to the hooks rather than lose the run
                 log("[rank %d] native RCCL set-up failed (%s): using the torch.distributed hooks" % (rank, e))
                 native = False
+            # every rank has to take the same path: one that fell back while the others did not would leave them waiting in a collective
+            agree = torch.tensor([1 if native else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if native and int(agree.item()) == 0:
+                log("[rank %d] another rank could not set up RCCL inside the library: using the torch.distributed hooks" % rank)
+                ctx.set_rccl(None)
+                native = False
         if not native:
             A.set_halo(plan, partition.make_halo(plan, on_device=True, host_staged=staged))
             ctx.set_allreduce(partition.make_allreduce(on_device=True, host_staged=staged))

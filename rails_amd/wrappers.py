@@ -75,6 +75,10 @@ class Context:
         assert len(unique_id) == 128
         check(self.lib.rails_ctx_init_rccl(self.h, C.c_char_p(unique_id), nranks, rank), "rails_ctx_init_rccl")
 
+    def set_rccl(self, comm):
+        """hand over an existing ncclComm_t (an integer address), or None to drop the communicator the context holds"""
+        check(self.lib.rails_ctx_set_rccl(self.h, C.c_void_p(comm) if comm else None), "rails_ctx_set_rccl")
+
     def rccl_size(self):
         return self.lib.rails_ctx_rccl_size(self.h)
 

@@ -122,5 +122,8 @@ def test_native_rccl_single_rank(oracle):
             Xg, Xo = V @ T @ V.T, out["V"] @ out["T"] @ out["V"].T
             assert np.linalg.norm(Xg - Xo) / np.linalg.norm(Xo) < 1e-4
             sv.close()
+        # dropping the communicator (bench.py's fall-back to the hooks when another rank could not set it up)
+        ctx.set_rccl(None)
+        assert ctx.rccl_size() == 0
     finally:
         ctx.close()
