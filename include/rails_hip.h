@@ -150,6 +150,10 @@ int rails_csr_set_variant(rails_csr *A, int variant);
 /* Statistics of the sweep kernel's schedule for nc columns, once a product of that width has built it:
  * out[0] slot efficiency, [1] X rows staged per matrix row and chunk, [2] lock-step trips, [3] 1 if the schedule exists. */
 int rails_csr_sweep_stats(rails_csr *A, int nc, double *out);
+/* A rectangular operator, n_rows x n_cols, all columns local: in rails_spmm X has n_cols rows and Y n_rows; no transposed apply, no
+ * ghost rows.  Role: the off-diagonal blocks A12, A21 of the reference's Schur complement operator (src/SchurOperator.cpp:181-214). */
+int rails_csr_create_rect(rails_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *rowptr, const int32_t *col, const double *val,
+                          rails_csr **out);
 /* name of the kernel the last rails_spmm on A launched */
 const char *rails_csr_last_kernel(const rails_csr *A);
 

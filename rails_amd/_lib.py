@@ -40,6 +40,7 @@ SIGNATURES = {
     "rails_ctx_rccl_size": (C.c_int, [_vp]),
     "rails_csr_set_halo_counts": (C.c_int, [_vp, C.c_int, _i64p, _i64p]),
     "rails_csr_create": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, _i32p, _dp, C.POINTER(_vp)]),
+    "rails_csr_create_rect": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, _i32p, _dp, C.POINTER(_vp)]),
     "rails_csr_create_callback": (C.c_int, [_vp, C.c_int64, APPLY_FN, _vp, C.POINTER(_vp)]),
     "rails_csr_destroy": (C.c_int, [_vp]),
     "rails_csr_rows": (C.c_int64, [_vp]),

@@ -131,6 +131,7 @@ struct rails_csr {
     rails_ctx *ctx = nullptr;
     rails_sweep_cache *sweep = nullptr;
     int64_t m = 0, ncols_ext = 0, nnz = 0;
+    bool rect = false; // rails_csr_create_rect: n_rows x n_cols with n_cols != n_rows, all columns local (X has ncols_ext rows, Y has m)
     int64_t *rowptr = nullptr;
     int32_t *col = nullptr;
     double *val = nullptr;

@@ -401,9 +401,22 @@ extern "C" int64_t rails_csr_rows(const rails_csr *A) { return A ? A->m : -1; }
 extern "C" int64_t rails_csr_nnz(const rails_csr *A) { return A ? A->nnz : -1; }
 extern "C" const char *rails_csr_last_kernel(const rails_csr *A) { return A ? A->last_kernel : ""; }
 
+// n_rows x n_cols with all columns local: X of a product has n_cols rows, Y n_rows.  The blocks A12, A21 of a Schur complement
+// (src/SchurOperator.cpp:181-214) are of this kind.  Plain row-gather kernels only (the tile and sweep plans assume a square operator).
+extern "C" int rails_csr_create_rect(rails_ctx *c, int64_t n_rows, int64_t n_cols, const int64_t *rowptr, const int32_t *col, const double *val,
+                                     rails_csr **out)
+{
+    RAILS_REQUIRE(n_cols >= 1, "rails_csr_create_rect: no columns");
+    RAILS_TRY(rails_csr_create(c, n_rows, n_cols, rowptr, col, val, out));
+    (*out)->rect = true;
+    (*out)->variant = 1;
+    return RAILS_OK;
+}
+
 extern "C" int rails_csr_set_variant(rails_csr *A, int variant)
 {
     RAILS_REQUIRE(A && variant >= 0 && variant <= 8, "rails_csr_set_variant: bad argument");
+    if (A->rect) return RAILS_OK; // rectangular operators stay on the plain row-gather kernel
     A->variant = variant;
     return RAILS_OK;
 }
@@ -462,8 +475,9 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     RAILS_REQUIRE(c && A && X && Y, "rails_spmm: null argument");
     RAILS_REQUIRE(xc0 >= 0 && nc >= 0 && xc0 + nc <= X->cap, "rails_spmm: X columns [%d,%d) outside capacity %d", xc0, xc0 + nc, X->cap);
     RAILS_REQUIRE(yc0 >= 0 && yc0 + nc <= Y->cap, "rails_spmm: Y columns [%d,%d) outside capacity %d", yc0, yc0 + nc, Y->cap);
-    RAILS_REQUIRE(X->m == A->m && Y->m == A->m, "rails_spmm: operator has %lld rows, X %lld, Y %lld", (long long)A->m, (long long)X->m,
-                  (long long)Y->m);
+    RAILS_REQUIRE(X->m == (A->rect ? A->ncols_ext : A->m) && Y->m == A->m, "rails_spmm: operator is %lld x %lld, X has %lld rows, Y %lld", (long long)A->m,
+                  (long long)(A->rect ? A->ncols_ext : A->m), (long long)X->m, (long long)Y->m);
+    RAILS_REQUIRE(!(A->rect && trans), "rails_spmm: a rectangular operator has no transposed apply (create the transposed matrix)");
     if (X->d == Y->d) RAILS_REQUIRE(xc0 + nc <= yc0 || yc0 + nc <= xc0, "rails_spmm: X and Y windows alias");
     if (nc == 0 || A->m == 0) return RAILS_OK;
     if (A->apply_cb) {
@@ -484,7 +498,9 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     }
     const double *Xp = X->d + xc0;
     double *Yp = Y->d + yc0;
-    const double *Xg = Xp;
+    // columns beyond the operator's rows come from the ghost buffer; for a rectangular operator (more columns than rows, all of them
+    // local) that buffer is the rest of X itself
+    const double *Xg = A->rect ? Xp + (size_t)std::min(A->m, A->ncols_ext) * X->ld : Xp;
     int ldg = X->ld;
     if (A->n_ghost > 0 || A->n_send > 0) {
         // pack the rows the neighbours need, exchange, gather from [local | ghost]

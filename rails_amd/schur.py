@@ -6,8 +6,9 @@ matrix is zero (algebraic constraints) and the set 2 where it is not; the operat
     S = A22 - A21 * A11^-1 * A12                                                   (src/SchurOperator.cpp:181-214)
 
 with a sparse LU factorisation of A11 (Amesos KLU there, SuperLU through scipy here, on the host like the reference's serial KLU).
-Here `S * X`: A22 * X is the CSR SpMM kernel on the device; the correction A21 (A11 \\ (A12 X)) goes through the host (download
-X, two sparse products and the LU solves, upload) and is subtracted on the device.  The operator plugs into the solver through
+Here `S * X`: A22 * X, A12 * X and A21 * Z are CSR SpMM kernels on the device (A12, A21 as rectangular operators, rails_csr_create_rect):
+X never leaves the device; what crosses PCIe per product is the m1 x nc block A12 X on its way to the LU solve and the solution Z on
+its way back (m1 = number of algebraic constraints).  The operator plugs into the solver through
 the C ABI's operator-callback handle (rails_csr_create_callback), so both back ends of the solver template run on it unchanged.
 Single rank, like the reference ("TODO: Fix these maps to work in parallel runs", src/SchurOperator.cpp:226).
 """
@@ -42,22 +43,35 @@ class SchurOperator:
         self.mass22 = d[self.idx2].copy()
         self.ctx = ctx
         self.A22 = HipOperatorWrapper(ctx, A22.indptr.astype(np.int64), A22.indices.astype(np.int32), A22.data.astype(np.float64))
+
+        def rect(Mx):
+            Mx = Mx.tocsr()
+            Mx.sort_indices()
+            return HipOperatorWrapper.rect(ctx, Mx.shape[0], Mx.shape[1], Mx.indptr.astype(np.int64), Mx.indices.astype(np.int32), Mx.data.astype(np.float64))
+
+        # the off-diagonal blocks and their transposes as device operators (a rectangular operator has no transposed apply)
+        self.dA12, self.dA21 = rect(self.A12), rect(self.A21)
+        self.dA12t, self.dA21t = rect(self.A12.T), rect(self.A21.T)
         self.applies = 0  # matrix-vector products, as SchurOperator::GetMVPs counts them
+        self.host_bytes = 0  # bytes that crossed PCIe in _apply (diagnostics)
         self.op = HipOperatorWrapper.from_callback(ctx, self.m2, self._apply)
 
     def _apply(self, trans, X, Y):
-        """Y = S X (or S' X): device SpMM with A22, host correction through the LU factors of A11"""
+        """Y = S X (or S' X): three device SpMMs; the LU solve with A11 on the host, on an m1 x nc block"""
         self.applies += X.n
         lib = self.ctx.lib
         check(lib.rails_spmm(self.ctx.h, self.A22.h.h, 1 if trans else 0, X.panel.h, X.c0, X.n, Y.panel.h, Y.c0), "rails_spmm")
-        Xh = X.to_host()
-        if not trans:
-            corr = self.A21 @ self.lu.solve(np.ascontiguousarray(self.A12 @ Xh))
-        else:  # S' = A22' - A12' A11^-T A21'
-            corr = self.A12.T @ self.lu.solve(np.ascontiguousarray(self.A21.T @ Xh), trans="T")
-        tmp = HipMultiVectorWrapper(self.ctx, data=np.asfortranarray(corr.reshape(self.m2, X.n)))
+        first, second = (self.dA12, self.dA21) if not trans else (self.dA21t, self.dA12t)  # S' = A22' - A12' A11^-T A21'
+        W = HipMultiVectorWrapper(self.ctx, self.m1, X.n, capacity=max(1, X.n))
+        check(lib.rails_spmm(self.ctx.h, first.h.h, 0, X.panel.h, X.c0, X.n, W.panel.h, 0), "rails_spmm")
+        Wh = W.to_host()
+        Z = self.lu.solve(np.ascontiguousarray(Wh), trans="T" if trans else "N")
+        self.host_bytes += 2 * Wh.nbytes
+        Zd = HipMultiVectorWrapper(self.ctx, data=np.asfortranarray(Z.reshape(self.m1, X.n)))
+        tmp = HipMultiVectorWrapper(self.ctx, self.m2, X.n, capacity=max(1, X.n))
+        check(lib.rails_spmm(self.ctx.h, second.h.h, 0, Zd.panel.h, 0, X.n, tmp.panel.h, 0), "rails_spmm")
         check(lib.rails_panel_axpy(self.ctx.h, -1.0, tmp.panel.h, 0, X.n, Y.panel.h, Y.c0), "rails_panel_axpy")
-        self.ctx.sync()  # tmp is released when this returns
+        self.ctx.sync()  # the temporaries are released when this returns
         return 0
 
     def restrict(self, B):

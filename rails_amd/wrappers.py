@@ -336,6 +336,20 @@ class HipOperatorWrapper:
         self.h = _Handle(ctx, h)
 
     @classmethod
+    def rect(cls, ctx, n_rows, n_cols, rowptr, col, val):
+        """A rectangular operator (include/rails_hip.h: rails_csr_create_rect): X of a product has n_cols rows, Y n_rows."""
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        assert rowptr.size == n_rows + 1
+        h = C.c_void_p()
+        check(ctx.lib.rails_csr_create_rect(ctx.h, n_rows, n_cols, rowptr.ctypes.data_as(C.POINTER(C.c_int64)), col.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            _p(val), C.byref(h)), "rails_csr_create_rect")
+        op = cls(ctx, None, None, None, _handle=_Handle(ctx, h))
+        op.n_rows, op.n_cols = n_rows, n_cols
+        return op
+
+    @classmethod
     def from_callback(cls, ctx, m, pyfunc):
         """An operator given by its action (include/rails_hip.h: rails_csr_create_callback): pyfunc(trans, X, Y) receives two
         HipMultiVectorWrapper views (m x nc windows of the library's panels) and must set Y = op(A) X."""
@@ -401,7 +415,7 @@ class HipOperatorWrapper:
     def apply(self, X, Y=None):
         """Y = op(A) * X (src/LyapunovSolver.hpp:146)."""
         if Y is None:
-            Y = HipMultiVectorWrapper(self.ctx, X.M(), X.n, capacity=max(1, X.n))
+            Y = HipMultiVectorWrapper(self.ctx, getattr(self, "n_rows", X.M()), X.n, capacity=max(1, X.n))
         check(self.ctx.lib.rails_spmm(self.ctx.h, self.h.h, 1 if self.trans else 0, X.panel.h, X.c0, X.n, Y.panel.h, Y.c0), "rails_spmm")
         return Y
 

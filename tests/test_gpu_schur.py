@@ -65,6 +65,32 @@ def test_operator_callback_handle():
     ctx.close()
 
 
+def test_rectangular_operators():
+    """rails_csr_create_rect: wide and tall CSR operators (the blocks A12, A21 of the Schur complement) against scipy, at the in-loop widths"""
+    import scipy.sparse as sp
+
+    import rails_amd
+    from rails_amd.wrappers import HipMultiVectorWrapper as MV
+
+    ctx = rails_amd.Context(device=0, seed=1)
+    g = np.random.default_rng(11)
+    for n_rows, n_cols in ((700, 2300), (2300, 700), (1, 50), (50, 1)):
+        Mx = sp.random(n_rows, n_cols, density=min(1.0, 12.0 / n_cols), random_state=3, format="csr")
+        Mx.sort_indices()
+        op = rails_amd.HipOperatorWrapper.rect(ctx, n_rows, n_cols, Mx.indptr.astype(np.int64), Mx.indices.astype(np.int32), Mx.data)
+        for nc in (1, 5, 16, 40):
+            Xh = g.uniform(-1, 1, (n_cols, nc))
+            Y = op.apply(MV(ctx, data=Xh))
+            assert Y.to_host().shape == (n_rows, nc)
+            ref = Mx @ Xh
+            assert np.abs(Y.to_host() - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
+        with pytest.raises(rails_amd.RailsError):
+            op.apply(MV(ctx, data=g.uniform(-1, 1, (n_cols + 1, 2))))  # X has to have n_cols rows
+        with pytest.raises(rails_amd.RailsError):
+            op.transpose().apply(MV(ctx, data=g.uniform(-1, 1, (n_cols, 2))))  # no transposed apply: create the transposed matrix
+    ctx.close()
+
+
 @pytest.mark.parametrize("subspace", [1, 0])
 def test_schur_operator_and_solve(subspace):
     import scipy.linalg as sl
@@ -87,6 +113,8 @@ def test_schur_operator_and_solve(subspace):
     Yt = S.op.transpose().apply(MV(ctx, data=Xh))
     np.testing.assert_allclose(Yt.to_host(), Sd.T @ Xh, atol=1e-12)
     assert S.applies == 10  # matrix-vector products through the operator, as SchurOperator::GetMVPs counts them
+    # X stayed on the device: per product only the m1 x nc block A12 X went to the host and the solution of the A11 system came back
+    assert S.host_bytes == 2 * 2 * S.m1 * 5 * 8 and S.m1 < S.m2
     # the Lyapunov equation on the Schur complement (what src/main.cpp:90-118 sets up): S X + X S' + B2 B2' = 0
     B2 = S.restrict(B)
     s = rails_amd.Solver(ctx, S.op, B2)
