@@ -62,6 +62,9 @@ constexpr int SWEEP_ACC0 = 24;
 #pragma clang diagnostic ignored "-Winline-asm"
 #define RAILS_SW_NAME k_spmm_sweep
 #define RAILS_SW_ABLATE 0 /* the product kernel: no experiment switches */
+#define RAILS_SW_PIPELINED 1
+#define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
+#define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -72,6 +75,22 @@ constexpr int SWEEP_ACC0 = 24;
 // the full kernel with the run-time experiment switches (RAILS_SWEEP_ABLATE & 7: no LDS-DMA / no trips / no barriers)
 #define RAILS_SW_NAME k_spmm_sweep_switches
 #define RAILS_SW_ABLATE a.ablate
+#define RAILS_SW_PIPELINED 1
+#define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
+#define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
+#define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
+#define RAILS_SW_FMA(TEXT) TEXT
+#define RAILS_SW_VMWAIT(TEXT) TEXT
+#define RAILS_SW_IDX(TEXT) TEXT
+#define RAILS_SW_DPPSFX "_dpp"
+#define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#include "spmm_sweep_kernel.inc"
+// experiment: the four trips of a unit as two separate halves (reads of two trips, their multiply-adds, then the next two)
+#define RAILS_SW_NAME k_spmm_sweep_halves
+#define RAILS_SW_ABLATE 0
+#define RAILS_SW_PIPELINED 0
+#define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
+#define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -82,6 +101,9 @@ constexpr int SWEEP_ACC0 = 24;
 // experiments: without the ring-row reads / the multiply-adds / the waits for the schedule stream
 #define RAILS_SW_NAME k_spmm_sweep_noread
 #define RAILS_SW_ABLATE a.ablate
+#define RAILS_SW_PIPELINED 0
+#define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
+#define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) ""
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -91,6 +113,9 @@ constexpr int SWEEP_ACC0 = 24;
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_nofma
 #define RAILS_SW_ABLATE a.ablate
+#define RAILS_SW_PIPELINED 0
+#define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
+#define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) ""
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -100,6 +125,9 @@ constexpr int SWEEP_ACC0 = 24;
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_nowait
 #define RAILS_SW_ABLATE a.ablate
+#define RAILS_SW_PIPELINED 0
+#define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
+#define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) ""
@@ -109,6 +137,9 @@ constexpr int SWEEP_ACC0 = 24;
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_noidx
 #define RAILS_SW_ABLATE a.ablate
+#define RAILS_SW_PIPELINED 0
+#define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
+#define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -118,6 +149,9 @@ constexpr int SWEEP_ACC0 = 24;
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_bare
 #define RAILS_SW_ABLATE a.ablate
+#define RAILS_SW_PIPELINED 0
+#define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
+#define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) ""
 #define RAILS_SW_FMA(TEXT) ""
 #define RAILS_SW_VMWAIT(TEXT) ""
@@ -127,6 +161,9 @@ constexpr int SWEEP_ACC0 = 24;
 #include "spmm_sweep_kernel.inc"
 #define RAILS_SW_NAME k_spmm_sweep_nodpp
 #define RAILS_SW_ABLATE a.ablate
+#define RAILS_SW_PIPELINED 0
+#define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
+#define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
 #define RAILS_SW_FMA(TEXT) TEXT
 #define RAILS_SW_VMWAIT(TEXT) TEXT
@@ -262,6 +299,7 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
     case 4: RAILS_SWEEP_LAUNCH(k_spmm_sweep_noidx); break;
     case 5: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nodpp); break;
     case 6: RAILS_SWEEP_LAUNCH(k_spmm_sweep_bare); break;
+    case 7: RAILS_SWEEP_LAUNCH(k_spmm_sweep_halves); break;
     default:
         if (ablate)
             RAILS_SWEEP_LAUNCH(k_spmm_sweep_switches);
