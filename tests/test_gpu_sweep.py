@@ -62,6 +62,39 @@ def test_sweep_is_bitwise_the_rowgather_result_and_matches_the_oracle(ctx, oracl
         assert np.array_equal(outp.to_host()[:, :yoff], np.zeros((m, yoff)))  # columns outside the window untouched
 
 
+@pytest.mark.parametrize("kind,nc", [("laplace7", 128), ("stencil27", 128), ("stencil27_random", 64), ("banded_narrow", 256)])
+def test_sweep_on_stencils_and_at_256_columns(ctx, kind, nc):
+    """Structured patterns (every row of a plane reads the same few offsets: many slots ask for neighbouring ring rows at once) and the widest
+    panel the kernel takes (16 column chunks x 2 phases: the window has to fit ONE block of 2816 rows): forced sweep against the row-gather
+    kernel, bit for bit."""
+    import rails_amd
+    from rails_amd import problems as P
+
+    if kind == "laplace7":
+        A = P.laplace7(50, 50, 60)  # window 2 * 2500 + 1 rows
+    elif kind == "stencil27":
+        A = P.stencil27(30, 30, 150)  # window 2 * 931 + 1
+    elif kind == "stencil27_random":
+        A = P.stencil27(40, 40, 90, random_values=True, seed=3)
+    else:
+        A = P.banded_random(140000, 27, 1000, seed=5)
+    m = A[0].size - 1
+    op = rails_amd.HipOperatorWrapper(ctx, *A)
+    Xh, X, Y, outp = _panels(ctx, m, nc, seed=nc + 1)
+    op.set_variant(7)
+    op.apply(X, Y)
+    assert op.last_kernel() == "k_spmm_sweep"
+    Ys = Y.to_host()
+    op.set_variant(3)
+    op.apply(X, Y)
+    assert op.last_kernel() == "k_spmm_rowgather"
+    assert np.array_equal(Ys, Y.to_host())
+    rp, col, val = A
+    rows = np.concatenate([np.arange(40), np.random.default_rng(2).choice(m, 2000, replace=False), np.arange(m - 40, m)])
+    ref = np.stack([val[rp[i]:rp[i + 1]] @ Xh[col[rp[i]:rp[i + 1]]] for i in rows])
+    assert np.abs(Ys[rows] - ref).max() <= 4e-14 * np.sqrt(27) * max(1.0, np.abs(ref).max())
+
+
 def test_sweep_handles_ragged_rows_and_rows_without_entries(ctx, oracle):
     import rails_amd
 
