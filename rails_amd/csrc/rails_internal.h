@@ -155,6 +155,7 @@ struct rails_csr {
     // LDS-staged footprint kernel (spmm.hip): per row-block column footprints
     int variant = 0;
     bool tiled_ready = false;
+    int is_grid = -1; // structured-grid stencil? (-1: not looked at yet; rails_csr_is_grid, spmm.hip)
     bool tiled_ok = false;
     int tile_rows = 0;
     int64_t n_tiles = 0;

@@ -177,3 +177,24 @@ def test_auto_choice_on_the_bench_matrix_and_its_transpose(ctx):
     AtZ = op.transpose().apply(Z)
     rhs = AtZ.dot(X)
     assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(lhs).max()
+
+
+def test_auto_leaves_structured_stencils_to_the_box_kernel(ctx):
+    """A 7-point Laplacian whose window fits the sweep's ring still goes to the LDS-staged box kernel in auto mode (few nonzeros per row
+    leave the sweep at its floor of one LDS-DMA latency per step: 0.82 against 0.65 ms at 50 x 50 x 400, 128 columns)"""
+    import rails_amd
+    from rails_amd import problems as P
+
+    A = P.laplace7(50, 50, 400)
+    m = A[0].size - 1
+    op = rails_amd.HipOperatorWrapper(ctx, *A)
+    X = rails_amd.HipMultiVectorWrapper(ctx, m=m, n=128, capacity=128)
+    X.random()
+    Y = op.apply(X)
+    assert op.last_kernel() == "k_spmm_tiled_reg"
+    op.set_variant(7)
+    Ys = op.apply(X)
+    assert op.last_kernel() == "k_spmm_sweep"
+    d = Y.copy()
+    d -= Ys
+    assert d.norm() <= 1e-13 * Y.norm()  # (the box kernel adds a row's terms in its own order)
