@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--cpu-trips", type=int, default=3, help="cpu_baseline: trips of the full-size CPU run that are timed")
     ap.add_argument("--cpu-warmup", type=int, default=5, help="cpu_baseline: trips of the full-size CPU run before the timed ones (at most --warmup)")
     ap.add_argument("--busy-steps", type=int, default=8, help="timed trips of the extra run with the GPU-busy meter on (0: skip it)")
+    ap.add_argument("--cpu-one-thread", type=int, default=1, help="cpu_baseline: also time one full-size trip on a single thread (0: skip)")
     ap.add_argument("--direct-steps", type=int, default=8, help="timed trips of the extra run on the direct back end (0: skip it)")
     ap.add_argument("--spmm-variant", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
@@ -405,6 +406,25 @@ def main():
                              "timed one by one after %d warm-up trips (%.2f s per trip; V has %d columns at the end)" % (
                                  orc.num_threads(), os.cpu_count() or 0, ml, Wc + 1, Wc + Kc, Wc, dt / Kc, out["V"].shape[1])}
             log("[cpu] full size, %d threads: trips %d..%d in %.2fs -> %.3f it/s" % (orc.num_threads(), Wc + 1, Wc + Kc, dt, cpu["value"]))
+            if args.cpu_one_thread:
+                # the same workload on ONE thread: two more trips, continued from the basis the run above ended with (the reference's warm start), the
+                # second one timed: a trip of the size of those timed above without repeating the warm-up on one thread
+                nthreads = orc.num_threads()
+                orc.set_num_threads(1)
+                try:
+                    t1 = time.perf_counter()
+                    out1 = orc.solve(As, Bs, orc.params({**params, "Restart from solution": 1, "rng_mode": 1, "seed": args.seed + 1, "max_trips": 2}),
+                                     V0=np.ascontiguousarray(out["V"]), vcap=args.restart + args.expand)
+                    t1 = time.perf_counter() - t1
+                    ts1 = out1["trip_seconds"]
+                    if ts1.size >= 2:
+                        d1 = float(ts1[1] - ts1[0])  # (the first trip of a warm start applies A to the whole basis: not a regular trip)
+                        cpu["one_thread"] = {"value": 1.0 / d1, "unit": "iterations/s", "cores": 1,
+                                             "sample": "the second trip of a run continued from the %d-column basis of the run above (%.2f s; the whole "
+                                                       "continuation took %.1f s)" % (out["V"].shape[1], d1, t1)}
+                        log("[cpu] full size, 1 thread: one trip in %.2fs -> %.3f it/s" % (d1, 1.0 / d1))
+                finally:
+                    orc.set_num_threads(nthreads)
         del out, As, Bs
 
     if rank == 0:
