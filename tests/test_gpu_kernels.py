@@ -425,3 +425,34 @@ def test_panel_gemm_wide_matches_numpy(ctx):
         np.testing.assert_allclose(Yv.to_host(), want, rtol=0, atol=1e-13 * k)
     # overlapping windows of one panel are refused
     assert ctx.lib.rails_panel_gemm_wide(ctx.h, 1.0, Y.panel.h, 0, 10, _p(Cm), k + 5, 20, 0.0, Y.panel.h, 5) != 0
+
+
+def test_busy_meter_counts_device_time(ctx):
+    """rails_ctx_set_meter: with the meter on, every launch is bracketed by events and `gpu_busy_ms` adds up the device time -- positive,
+    below the wall-clock time of the same work, and unchanged while the meter is off."""
+    import time
+
+    import rails_amd
+
+    X = rails_amd.HipMultiVectorWrapper(ctx, m=400000, n=64, capacity=64)
+    X.random()
+    ctx.sync()
+    base = ctx.stats()["gpu_busy_ms"]
+    G = X.dot(X)
+    ctx.sync()
+    assert ctx.stats()["gpu_busy_ms"] == base  # meter off: nothing is counted
+    ctx.set_meter(True)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        G = X.dot(X)
+    ctx.sync()
+    wall_ms = 1e3 * (time.perf_counter() - t0)
+    busy = ctx.stats()["gpu_busy_ms"] - base
+    ctx.set_meter(False)
+    assert 0.0 < busy <= wall_ms, (busy, wall_ms)
+    assert busy > 5 * 0.02  # five Gram launches over 200 MB each take longer than 20 us apiece
+    after = ctx.stats()["gpu_busy_ms"]
+    G2 = X.dot(X)
+    ctx.sync()
+    assert ctx.stats()["gpu_busy_ms"] == after
+    np.testing.assert_allclose(G2, G, rtol=0, atol=0)
