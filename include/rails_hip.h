@@ -209,6 +209,21 @@ int rails_gram(rails_ctx *ctx, const rails_panel *X, int xc0, int a, const rails
  * column windows coincide exactly (in-place, row-local) or are disjoint. */
 int rails_panel_gemm(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int k, const double *C_host,
                      int ldc, int r, double beta, rails_panel *Y, int yc0);
+
+/* Deferred small results: a chain Gram -> update -> Gram -> Cholesky -> update on the device without the host in between (the block
+ * orthogonalisation of the coordinate-space back end behind the host's projected solve).  An arena of `nslots` slots of
+ * `doubles_per_slot` doubles on the device with a pinned mirror; rails_gram_deferred leaves X'Y (a x b, leading dimension a, summed
+ * over the ranks) in a slot and sends it on its way to the mirror; rails_panel_gemm_deferred takes the coefficient matrix of
+ * Y = beta Y + alpha X C from a slot (rows [0, k) of its r columns, leading dimension ld); rails_chol_inverse_deferred turns the w x w
+ * Gram matrix G of a slot (w <= 32) into D^-1 R^-1 (D = sqrt(diag G), R'R = D^-1 G D^-1) in another slot.  None of them synchronises;
+ * rails_deferred_fetch copies from the mirror and is valid after a rails_ctx_sync that follows the call which filled the slot. */
+int rails_deferred_reserve(rails_ctx *ctx, int nslots, int64_t doubles_per_slot);
+int rails_gram_deferred(rails_ctx *ctx, const rails_panel *X, int xc0, int a, const rails_panel *Y, int yc0, int b, int slot);
+int rails_panel_gemm_deferred(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int k, int slot, int ld, int r, double beta,
+                              rails_panel *Y, int yc0);
+int rails_chol_inverse_deferred(rails_ctx *ctx, int slot_in, int w, int slot_out);
+int rails_deferred_fetch(rails_ctx *ctx, int slot, int64_t n, double *host_out);
+
 /* The same product for any number r of output columns: one upload of C, launches in slices of 128 columns with no host wait in
  * between (the basis rotation of the coordinate-space back end).  X and Y: different panels or disjoint windows. */
 int rails_panel_gemm_wide(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc, int r,

@@ -29,6 +29,11 @@ SIGNATURES = {
     "rails_ctx_sync": (C.c_int, [_vp]),
     "rails_ctx_stream": (_vp, [_vp]),
     "rails_ctx_set_meter": (C.c_int, [_vp, C.c_int]),
+    "rails_deferred_reserve": (C.c_int, [_vp, C.c_int, C.c_int64]),
+    "rails_gram_deferred": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
+    "rails_panel_gemm_deferred": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int]),
+    "rails_chol_inverse_deferred": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "rails_deferred_fetch": (C.c_int, [_vp, C.c_int, C.c_int64, _dp]),
     "rails_ctx_stats": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "rails_ctx_set_seed": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "rails_ctx_rng_state": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

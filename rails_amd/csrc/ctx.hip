@@ -77,6 +77,8 @@ extern "C" int rails_ctx_destroy(rails_ctx *c)
     if (c->ws) hipFree(c->ws);
     if (c->small) hipFree(c->small);
     if (c->pinned) hipHostFree(c->pinned);
+    if (c->defer_dev) hipFree(c->defer_dev);
+    if (c->defer_pin) hipHostFree(c->defer_pin);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev_h2d) hipEventDestroy(c->ev_h2d);

@@ -395,6 +395,147 @@ extern "C" int rails_gram(rails_ctx *c, const rails_panel *X, int xc0, int a, co
     return RAILS_OK;
 }
 
+// ---- deferred small results --------------------------------------------------------------------------------------------------
+// The block orthogonalisation of the coordinate-space back end is a chain Gram -> update -> Gram -> Cholesky -> update ... whose small
+// matrices the host only needs for bookkeeping.  With these entry points the chain runs on the device without the host in between:
+// a Gram result stays in a slot of a device arena (and is copied to its pinned mirror, to be read after a later synchronisation), the
+// next update takes its coefficients from the slot, the Cholesky factor of a w x w slot is inverted into another slot by a small
+// kernel.  Nothing here synchronises.
+
+namespace {
+
+// rows [0, k) of the r columns of a slot (leading dimension ld) packed into k x r
+__global__ void k_compact_cols(const double *__restrict__ src, int ld, int k, int r, double *__restrict__ dst)
+{
+    const int64_t n = (int64_t)k * r;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) dst[q] = src[(q / k) * ld + (q % k)];
+}
+
+// G (w x w, symmetric positive definite, w <= 32) -> M = D^-1 R^-1 with D = sqrt(diag G), R'R = D^-1 G D^-1 (upper triangular):
+// X M has orthonormal columns when X'X = G.  One thread: ~w^3 / 2 dependent operations, a few microseconds, off the critical path.
+// A G that is not positive definite gives NaNs (the host repeats the factorisation on its copy of G and decides).
+__global__ void k_small_chol(const double *__restrict__ G, int w, double *__restrict__ M)
+{
+    __shared__ double S[32 * 33], Ri[32 * 33], d[32];
+    const int t = threadIdx.x;
+    for (int q = t; q < w * w; q += blockDim.x) S[(q / w) * 33 + (q % w)] = G[q]; // S[col][row]
+    __syncthreads();
+    if (t == 0) {
+        for (int j = 0; j < w; ++j) d[j] = sqrt(S[j * 33 + j]);
+        for (int j = 0; j < w; ++j)
+            for (int i = 0; i < w; ++i) S[j * 33 + i] /= d[i] * d[j];
+        // upper Cholesky, column by column, in place (R[i][j] for i <= j at S[j][i])
+        for (int j = 0; j < w; ++j) {
+            for (int i = 0; i < j; ++i) {
+                double s = S[j * 33 + i];
+                for (int l = 0; l < i; ++l) s -= S[i * 33 + l] * S[j * 33 + l];
+                S[j * 33 + i] = s / S[i * 33 + i];
+            }
+            double s = S[j * 33 + j];
+            for (int l = 0; l < j; ++l) s -= S[j * 33 + l] * S[j * 33 + l];
+            S[j * 33 + j] = sqrt(s);
+        }
+        // inverse of the upper triangular factor
+        for (int j = 0; j < w; ++j) {
+            Ri[j * 33 + j] = 1.0 / S[j * 33 + j];
+            for (int i = j - 1; i >= 0; --i) {
+                double s = 0.0;
+                for (int l = i + 1; l <= j; ++l) s += S[l * 33 + i] * Ri[j * 33 + l];
+                Ri[j * 33 + i] = -s / S[i * 33 + i];
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = t; q < w * w; q += blockDim.x) {
+        const int j = q / w, i = q % w;
+        M[q] = i <= j ? Ri[j * 33 + i] / d[i] : 0.0;
+    }
+}
+
+} // namespace
+
+extern "C" int rails_deferred_reserve(rails_ctx *c, int nslots, int64_t doubles_per_slot)
+{
+    RAILS_REQUIRE(c && nslots >= 1 && doubles_per_slot >= 1, "rails_deferred_reserve: bad argument");
+    hipSetDevice(c->device);
+    if (c->defer_dev && c->defer_nslots >= nslots && c->defer_slot >= (size_t)doubles_per_slot) return RAILS_OK;
+    RAILS_HIP_CHECK(rails_stream_sync(c));
+    if (c->defer_dev) hipFree(c->defer_dev);
+    if (c->defer_pin) hipHostFree(c->defer_pin);
+    c->defer_dev = c->defer_pin = nullptr;
+    const size_t slot = ((size_t)doubles_per_slot * 3 / 2 + 63) / 64 * 64, bytes = slot * (size_t)nslots * sizeof(double);
+    c->n_dev_alloc++;
+    RAILS_HIP_CHECK(hipMalloc((void **)&c->defer_dev, bytes));
+    RAILS_HIP_CHECK(hipHostMalloc((void **)&c->defer_pin, bytes, hipHostMallocDefault));
+    c->defer_slot = slot;
+    c->defer_nslots = nslots;
+    return RAILS_OK;
+}
+
+#define RAILS_SLOT_CHECK(slot, n, what)                                                                                                    \
+    RAILS_REQUIRE(c && c->defer_dev && (slot) >= 0 && (slot) < c->defer_nslots && (size_t)(n) <= c->defer_slot,                            \
+                  what ": slot %d / %lld doubles outside the arena (rails_deferred_reserve)", (int)(slot), (long long)(n))
+
+// slot <- X[:, xc0:xc0+a]' * Y[:, yc0:yc0+b] (a x b, column-major, leading dimension a), summed over the ranks; also on its way to the
+// pinned mirror of the slot
+extern "C" int rails_gram_deferred(rails_ctx *c, const rails_panel *X, int xc0, int a, const rails_panel *Y, int yc0, int b, int slot)
+{
+    if (c) hipSetDevice(c->device);
+    RAILS_REQUIRE(c && X && Y, "rails_gram_deferred: null argument");
+    RAILS_REQUIRE(a >= 1 && b >= 1 && xc0 >= 0 && yc0 >= 0 && xc0 + a <= X->cap && yc0 + b <= Y->cap && X->m == Y->m, "rails_gram_deferred: bad windows");
+    const size_t n = (size_t)a * b;
+    RAILS_SLOT_CHECK(slot, n, "rails_gram_deferred");
+    double *out = c->defer_dev + (size_t)slot * c->defer_slot;
+    if (X->m > 0)
+        RAILS_TRY(rails_gram_dev(c, X->d + xc0, X->ld, Y->d + yc0, Y->ld, X->m, a, b, out));
+    else
+        RAILS_HIP_CHECK(hipMemsetAsync(out, 0, n * sizeof(double), c->stream));
+    RAILS_TRY(rails_allreduce_dev(c, out, n));
+    RAILS_HIP_CHECK(hipMemcpyAsync(c->defer_pin + (size_t)slot * c->defer_slot, out, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return RAILS_OK;
+}
+
+// Y[:, yc0:yc0+r] = beta Y + alpha X[:, xc0:xc0+k] * C, C = rows [0, k) of the r columns held in a slot with leading dimension ld
+extern "C" int rails_panel_gemm_deferred(rails_ctx *c, double alpha, const rails_panel *X, int xc0, int k, int slot, int ld, int r, double beta,
+                                         rails_panel *Y, int yc0)
+{
+    if (c) hipSetDevice(c->device);
+    RAILS_REQUIRE(c && X && Y, "rails_panel_gemm_deferred: null argument");
+    RAILS_REQUIRE(k >= 1 && r >= 1 && r <= 256 && ld >= k && xc0 >= 0 && yc0 >= 0 && xc0 + k <= X->cap && yc0 + r <= Y->cap && X->m == Y->m,
+                  "rails_panel_gemm_deferred: bad shapes");
+    RAILS_SLOT_CHECK(slot, (size_t)ld * r, "rails_panel_gemm_deferred");
+    if (X->d == Y->d) RAILS_REQUIRE(xc0 == yc0 || xc0 + k <= yc0 || yc0 + r <= xc0, "rails_panel_gemm_deferred: partially overlapping windows of one panel");
+    if (X->m == 0) return RAILS_OK;
+    const double *C = c->defer_dev + (size_t)slot * c->defer_slot;
+    if (ld != k) {
+        RAILS_TRY(rails_small_reserve(c, (size_t)k * r * sizeof(double)));
+        RAILS_LAUNCH(k_compact_cols, dim3((unsigned)std::min<int64_t>(256, ((int64_t)k * r + 255) / 256)), dim3(256), 0, c->stream, C, ld, k, r, c->small);
+        C = c->small;
+    }
+    return rails_panel_gemm_dev(c, alpha, X->d + xc0, X->ld, k, C, r, beta, Y->d + yc0, Y->ld, X->m);
+}
+
+// slot_out <- D^-1 R^-1 for the w x w Gram matrix in slot_in (see k_small_chol)
+extern "C" int rails_chol_inverse_deferred(rails_ctx *c, int slot_in, int w, int slot_out)
+{
+    if (c) hipSetDevice(c->device);
+    RAILS_REQUIRE(c && w >= 1 && w <= 32 && slot_in != slot_out, "rails_chol_inverse_deferred: bad argument (w = %d)", w);
+    RAILS_SLOT_CHECK(slot_in, (size_t)w * w, "rails_chol_inverse_deferred");
+    RAILS_SLOT_CHECK(slot_out, (size_t)w * w, "rails_chol_inverse_deferred");
+    RAILS_LAUNCH(k_small_chol, dim3(1), dim3(64), 0, c->stream, c->defer_dev + (size_t)slot_in * c->defer_slot, w, c->defer_dev + (size_t)slot_out * c->defer_slot);
+    RAILS_HIP_CHECK(hipGetLastError());
+    return RAILS_OK;
+}
+
+// the first n doubles of a slot's pinned mirror (valid once the stream has been synchronised after the call that filled the slot)
+extern "C" int rails_deferred_fetch(rails_ctx *c, int slot, int64_t n, double *host_out)
+{
+    RAILS_REQUIRE(host_out && n >= 0, "rails_deferred_fetch: bad argument");
+    RAILS_SLOT_CHECK(slot, n, "rails_deferred_fetch");
+    memcpy(host_out, c->defer_pin + (size_t)slot * c->defer_slot, (size_t)n * sizeof(double));
+    return RAILS_OK;
+}
+
 int rails_panel_gemm_dev(rails_ctx *c, double alpha, const double *X, int ldx, int k, const double *C_dev, int r, double beta,
                          double *Y, int ldy, int64_t m)
 {

@@ -76,6 +76,10 @@ struct rails_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_h2d = nullptr; // recorded after an asynchronous upload out of `pinned`; waited for before the host writes there again
     bool h2d_pending = false;
+    // deferred small results (dense.hip: rails_gram_deferred ...): slots of `defer_slot` doubles on the device with a pinned mirror
+    double *defer_dev = nullptr, *defer_pin = nullptr;
+    size_t defer_slot = 0;
+    int defer_nslots = 0;
     // busy meter (rails_ctx_set_meter): a pair of events around every launch; the pairs are read at the next synchronisation of the stream
     bool meter = false;
     std::vector<hipEvent_t> meter_events; // 2 x RAILS_METER_PAIRS

@@ -91,6 +91,24 @@ public:
     bool cached_valid = false;
     bool prefetch_random = true;
 
+    // ---- overlapped block orthogonalisation ------------------------------------------------------------------------------------
+    // After the first projection round of a block the host knows the block's coordinates to ~1e-12 (first-round coefficients, Gram
+    // matrix by Pythagoras): enough to go on with the projected solve and the residual Lanczos run, which only steer the iteration.  The
+    // second round and the CholQR of the block run on the device meanwhile (the deferred entry points of rails_hip.h: no host decision
+    // sits in between); when the basis is next needed -- the coming A*W -- the small matrices they produced are read back and every live
+    // coefficient store is re-based from the predicted new basis columns to the real ones (a w x w and a dim x w map, exact).
+    // RAILS_SUBSPACE_OVERLAP=0 switches it off (every block then waits for its own orthogonalisation, as in round 1).
+    bool overlap = !(getenv("RAILS_SUBSPACE_OVERLAP") && atoi(getenv("RAILS_SUBSPACE_OVERLAP")) == 0);
+    double overlap_min_survival = 1e-4; // below: rounding in the Pythagorean Gram matrix (eps / survival) is no longer negligible
+    long n_overlapped = 0;
+    struct Pending {
+        bool active = false;
+        int dim0 = 0, w = 0, w2 = 0;
+        std::vector<double> Rfp;    // predicted R factor (w x w, upper): coordinates of the block along the new basis columns
+        std::vector<double> g0diag; // squared lengths of the block's columns before any projection
+    } pending;
+    enum { SLOT_C2 = 0, SLOT_G = 1, SLOT_M1 = 2, SLOT_G2 = 3, SLOT_M2 = 4, N_SLOTS = 5 };
+
     SubspaceBasis(rails_ctx *c, int64_t ml, int64_t mg, int rows) : ctx(c), m_local(ml), m_global(mg), P(ml, std::max(rows, 16), c), row_cap(std::max(rows, 16))
     {
         P.set_global_rows(mg);
@@ -139,6 +157,7 @@ public:
             scratch = HipMultiVectorWrapper(m_local, std::max(n, 16), ctx);
             scratch.set_global_rows(m_global);
         }
+        if (!resolve_pending()) return scratch;
         scratch.resize(n);
         HipMultiVectorWrapper out;
         out = scratch; // shares the panel
@@ -173,6 +192,7 @@ public:
     // the extended basis.  Block CGS2 against P, CholQR2 inside the block; the representation is X = P_old (C1 + C2) + Q (R2 R1).
     bool absorb_tail(int w, double *coef)
     {
+        if (!resolve_pending()) return false;
         n_absorb++;
         n_absorb_cols += w;
         if (w <= 0) return true;
@@ -221,6 +241,7 @@ public:
                     if (!(surv > reorth_survival)) w2 = j + 1;
                 }
                 if (trace) std::cerr << "absorb: dim " << dim << " w " << w << " first round: smallest survival " << worst << ", second round on " << w2 << " columns" << std::endl;
+                if (overlap && w <= 32 && worst >= overlap_min_survival && start_overlapped(w, w2, coef, CG, G0)) return true;
                 if (w2 == 0) break;
                 n_second_round++;
                 if (w2 < w) { // keep what the Gram entries of the untouched columns need
@@ -355,6 +376,7 @@ public:
     // live multivector; directions no live object uses any more (stale Lanczos start vectors, pre-restart V and AV) go away.
     void compress()
     {
+        if (!resolve_pending()) return;
         std::vector<std::shared_ptr<CoefStore>> stores;
         std::vector<std::weak_ptr<CoefStore>> still;
         int ncols = 0;
@@ -439,6 +461,156 @@ public:
         std::swap(P, P2);
         dim = rank;
         n_compress++;
+    }
+
+    // The first round of a block has been applied (X <- X - P C1 is queued, coef holds C1): predict the block's coordinates along its
+    // own new basis columns, queue the rest of the orthogonalisation on the device, and return without waiting.  false: conditions not
+    // met (nothing was queued; the caller goes on in the ordinary way).
+    bool start_overlapped(int w, int w2, double *coef, std::vector<double> const &CG, std::vector<double> const &G0)
+    {
+        const int ld = row_cap, dw = dim + w;
+        // Gram matrix of the projected block by Pythagoras, its scaled Cholesky factor
+        std::vector<double> Gp((size_t)w * w), d(w);
+        for (int j = 0; j < w; ++j)
+            for (int i = 0; i <= j; ++i) {
+                double s = 0.0;
+                for (int l = 0; l < dim; ++l) s += CG[l + (size_t)i * dw] * CG[l + (size_t)j * dw];
+                Gp[i + (size_t)j * w] = Gp[j + (size_t)i * w] = G0[i + (size_t)j * w] - s;
+            }
+        for (int j = 0; j < w; ++j) {
+            if (!(Gp[j + (size_t)j * w] > 1e-8 * G0[j + (size_t)j * w]) || !(Gp[j + (size_t)j * w] > 0.0)) return false;
+            d[j] = std::sqrt(Gp[j + (size_t)j * w]);
+        }
+        std::vector<double> R1((size_t)w * w);
+        for (int b = 0; b < w; ++b)
+            for (int a = 0; a < w; ++a) R1[a + (size_t)b * w] = Gp[a + (size_t)b * w] / (d[a] * d[b]);
+        int info = 0;
+        rails_dpotrf('U', w, R1.data(), w, &info);
+        if (info != 0) return false;
+        for (int a = 0; a < w; ++a)
+            if (!(R1[a + (size_t)a * w] > 1e-2)) return false; // an ill-conditioned block takes the careful way (re-projection)
+        if (!hip_ok(rails_deferred_reserve(ctx, N_SLOTS, (int64_t)(P.capacity() + 64) * 32), "rails_deferred_reserve")) return false;
+        // the device's part, queued behind the first update: second round on the leading w2 columns, Gram matrix of the block, its
+        // Cholesky factor inverted, Q1 = X M1, the same once more (CholQR2)
+        rails_panel *pp = P.panel();
+        bool ok = true;
+        if (w2 > 0) {
+            ok = ok && hip_ok(rails_gram_deferred(ctx, pp, 0, dim, pp, dim, w2, SLOT_C2), "rails_gram_deferred");
+            ok = ok && hip_ok(rails_panel_gemm_deferred(ctx, -1.0, pp, 0, dim, SLOT_C2, dim, w2, 1.0, pp, dim), "rails_panel_gemm_deferred");
+        }
+        ok = ok && hip_ok(rails_gram_deferred(ctx, pp, dim, w, pp, dim, w, SLOT_G), "rails_gram_deferred");
+        ok = ok && hip_ok(rails_chol_inverse_deferred(ctx, SLOT_G, w, SLOT_M1), "rails_chol_inverse_deferred");
+        ok = ok && hip_ok(rails_panel_gemm_deferred(ctx, 1.0, pp, dim, w, SLOT_M1, w, w, 0.0, pp, dim), "rails_panel_gemm_deferred");
+        ok = ok && hip_ok(rails_gram_deferred(ctx, pp, dim, w, pp, dim, w, SLOT_G2), "rails_gram_deferred");
+        ok = ok && hip_ok(rails_chol_inverse_deferred(ctx, SLOT_G2, w, SLOT_M2), "rails_chol_inverse_deferred");
+        ok = ok && hip_ok(rails_panel_gemm_deferred(ctx, 1.0, pp, dim, w, SLOT_M2, w, w, 0.0, pp, dim), "rails_panel_gemm_deferred");
+        if (!ok) return fail("the overlapped block orthogonalisation could not be queued"), true;
+        // predicted coordinates along the new columns: X = Q Rfp, Rfp = R1 D
+        pending.active = true;
+        pending.dim0 = dim;
+        pending.w = w;
+        pending.w2 = w2;
+        pending.Rfp.assign((size_t)w * w, 0.0);
+        pending.g0diag.resize(w);
+        for (int b = 0; b < w; ++b) {
+            pending.g0diag[b] = G0[b + (size_t)b * w];
+            for (int a = 0; a <= b; ++a) {
+                pending.Rfp[a + (size_t)b * w] = R1[a + (size_t)b * w] * d[b];
+                coef[(dim + a) + (size_t)b * ld] = pending.Rfp[a + (size_t)b * w];
+            }
+        }
+        if (w2 > 0) n_second_round++;
+        n_overlapped++;
+        dim += w;
+        P.resize(dim);
+        return true;
+    }
+
+    // Read back what the queued orthogonalisation produced and move every live coefficient store from the predicted new basis columns to
+    // the real ones: with X = P (C1 + C2) + Q Rft the truth and (C1, Rfp) what was booked, a vector with booked coordinates
+    // (a_old, a_new) is P (a_old + C2 Rfp^-1 a_new) + Q (Rft Rfp^-1 a_new).
+    bool resolve_pending()
+    {
+        if (!pending.active) return !failed;
+        pending.active = false;
+        const int d0 = pending.dim0, w = pending.w, w2 = pending.w2;
+        if (!hip_ok(rails_ctx_sync(ctx), "rails_ctx_sync")) return fail();
+        std::vector<double> C2((size_t)d0 * w, 0.0), G((size_t)w * w), G2((size_t)w * w);
+        bool ok = true;
+        if (w2 > 0) ok = ok && hip_ok(rails_deferred_fetch(ctx, SLOT_C2, (int64_t)d0 * w2, C2.data()), "rails_deferred_fetch");
+        ok = ok && hip_ok(rails_deferred_fetch(ctx, SLOT_G, (int64_t)w * w, G.data()), "rails_deferred_fetch");
+        ok = ok && hip_ok(rails_deferred_fetch(ctx, SLOT_G2, (int64_t)w * w, G2.data()), "rails_deferred_fetch");
+        if (!ok) return fail();
+        // the factors the device applied, repeated on the host's copies of the two Gram matrices
+        auto factor = [&](std::vector<double> const &Gm, std::vector<double> &R, std::vector<double> &dd) {
+            dd.resize(w);
+            R.assign((size_t)w * w, 0.0);
+            for (int j = 0; j < w; ++j) {
+                if (!(Gm[j + (size_t)j * w] > 0.0) || !std::isfinite(Gm[j + (size_t)j * w])) return false;
+                dd[j] = std::sqrt(Gm[j + (size_t)j * w]);
+            }
+            for (int b = 0; b < w; ++b)
+                for (int a = 0; a < w; ++a) R[a + (size_t)b * w] = Gm[a + (size_t)b * w] / (dd[a] * dd[b]);
+            int inf = 0;
+            rails_dpotrf('U', w, R.data(), w, &inf);
+            if (inf != 0) return false;
+            for (int b = 0; b < w; ++b)
+                for (int a = b + 1; a < w; ++a) R[a + (size_t)b * w] = 0.0;
+            return true;
+        };
+        std::vector<double> R1, d1, R2, d2;
+        if (!factor(G, R1, d1) || !factor(G2, R2, d2)) return fail("the overlapped block orthogonalisation met a block that is not of full rank");
+        for (int j = 0; j < w; ++j)
+            if (!(G[j + (size_t)j * w] > 1e-8 * pending.g0diag[j]) || !(R1[j + (size_t)j * w] > 1e-6))
+                return fail("the overlapped block orthogonalisation met a block it should have treated with care");
+        // Rft = (R2 D2) (R1 D1), upper triangular
+        std::vector<double> Rft((size_t)w * w, 0.0);
+        for (int b = 0; b < w; ++b)
+            for (int a = 0; a <= b; ++a) {
+                double sum = 0.0;
+                for (int l = a; l <= b; ++l) sum += R2[a + (size_t)l * w] * d2[l] * R1[l + (size_t)b * w];
+                Rft[a + (size_t)b * w] = sum * d1[b];
+            }
+        // Tn = Rft Rfp^-1 (w x w, upper), To = [C2 0] Rfp^-1 (d0 x w)
+        std::vector<double> Rpi((size_t)w * w, 0.0), Tn((size_t)w * w, 0.0), To((size_t)d0 * w, 0.0);
+        upper_inverse(pending.Rfp, w, Rpi);
+        double off = 0.0;
+        for (int b = 0; b < w; ++b)
+            for (int a = 0; a <= b; ++a) {
+                double sum = 0.0;
+                for (int l = a; l <= b; ++l) sum += Rft[a + (size_t)l * w] * Rpi[l + (size_t)b * w];
+                Tn[a + (size_t)b * w] = sum;
+                off = std::max(off, std::fabs(sum - (a == b ? 1.0 : 0.0)));
+            }
+        if (!(off < 1e-4)) return fail("the overlapped block orthogonalisation did not confirm its prediction");
+        if (w2 > 0) rails_dgemm('N', 'N', d0, w, w2, 1.0, C2.data(), d0, Rpi.data(), w, 0.0, To.data(), d0);
+        if (trace) std::cerr << "absorb (overlapped): dim " << d0 << " w " << w << ": prediction off by " << off << std::endl;
+        std::vector<double> an(w), bn(w);
+        for (auto &wk : live)
+            if (auto st = wk.lock()) {
+                for (int j = 0; j < st->ncap; ++j) {
+                    double *cj = st->col(j);
+                    bool nz = false;
+                    for (int a = 0; a < w; ++a) {
+                        an[a] = cj[d0 + a];
+                        nz = nz || an[a] != 0.0;
+                    }
+                    if (!nz) continue;
+                    if (w2 > 0)
+                        for (int a = 0; a < w; ++a) {
+                            if (an[a] == 0.0) continue;
+                            const double *t = To.data() + (size_t)a * d0;
+                            for (int i = 0; i < d0; ++i) cj[i] += t[i] * an[a];
+                        }
+                    for (int a = 0; a < w; ++a) {
+                        double sum = 0.0;
+                        for (int l = a; l < w; ++l) sum += Tn[a + (size_t)l * w] * an[l];
+                        bn[a] = sum;
+                    }
+                    for (int a = 0; a < w; ++a) cj[d0 + a] = bn[a];
+                }
+            }
+        return !failed;
     }
 
 private:
