@@ -524,6 +524,8 @@ extern "C" int rails_chol_inverse_deferred(rails_ctx *c, int slot_in, int w, int
     RAILS_SLOT_CHECK(slot_out, (size_t)w * w, "rails_chol_inverse_deferred");
     RAILS_LAUNCH(k_small_chol, dim3(1), dim3(64), 0, c->stream, c->defer_dev + (size_t)slot_in * c->defer_slot, w, c->defer_dev + (size_t)slot_out * c->defer_slot);
     RAILS_HIP_CHECK(hipGetLastError());
+    RAILS_HIP_CHECK(hipMemcpyAsync(c->defer_pin + (size_t)slot_out * c->defer_slot, c->defer_dev + (size_t)slot_out * c->defer_slot, (size_t)w * w * sizeof(double),
+                                   hipMemcpyDeviceToHost, c->stream)); // (the mirror: diagnostics and tests)
     return RAILS_OK;
 }
 

@@ -456,3 +456,48 @@ def test_busy_meter_counts_device_time(ctx):
     ctx.sync()
     assert ctx.stats()["gpu_busy_ms"] == after
     np.testing.assert_allclose(G2, G, rtol=0, atol=0)
+
+
+def test_deferred_small_results(ctx):
+    """rails_gram_deferred / rails_panel_gemm_deferred / rails_chol_inverse_deferred (include/rails_hip.h): the chain the coordinate-space
+    back end queues behind the host's projected solve -- Gram into a device slot, an update whose coefficients come from that slot, the
+    scaled Cholesky factor of a block's Gram matrix inverted on the device -- against numpy, with ONE synchronisation at the end."""
+    import ctypes as C
+
+    import rails_amd
+
+    lib = ctx.lib
+    g = np.random.default_rng(21)
+    m, a, w = 50000, 24, 17
+    Xh = g.uniform(-1, 1, (m, a + w))
+    # make the last w columns nearly lie in the span of the first a: what a projection round sees
+    Xh[:, a:] = Xh[:, :a] @ g.uniform(-1, 1, (a, w)) + 0.05 * g.uniform(-1, 1, (m, w))
+    X = rails_amd.HipMultiVectorWrapper(ctx, data=Xh)
+    P = X.panel.h
+    rails_amd._lib.check(lib.rails_deferred_reserve(ctx.h, 5, (a + w) * w), "rails_deferred_reserve")
+    chk = rails_amd._lib.check
+    chk(lib.rails_gram_deferred(ctx.h, P, 0, a + w, P, a, w, 0), "gram")                 # slot 0: [Xa | Xw]' Xw, leading dimension a + w
+    chk(lib.rails_panel_gemm_deferred(ctx.h, -1.0, P, 0, a, 0, a + w, w, 1.0, P, a), "update")  # Xw -= Xa * (top a rows of slot 0)
+    chk(lib.rails_gram_deferred(ctx.h, P, a, w, P, a, w, 1), "gram")                      # slot 1: Gram matrix of the updated block
+    chk(lib.rails_chol_inverse_deferred(ctx.h, 1, w, 2), "chol")                          # slot 2: D^-1 R^-1
+    chk(lib.rails_panel_gemm_deferred(ctx.h, 1.0, P, a, w, 2, w, w, 0.0, P, a), "scale")    # Xw <- Xw * slot 2 (in place)
+    chk(lib.rails_gram_deferred(ctx.h, P, a, w, P, a, w, 3), "gram")                      # slot 3: should be the identity
+    ctx.sync()
+    dp = C.POINTER(C.c_double)
+
+    def fetch(slot, rows, cols):
+        out = np.zeros((rows, cols), order="F")
+        chk(lib.rails_deferred_fetch(ctx.h, slot, rows * cols, out.ctypes.data_as(dp)), "fetch")
+        return out
+
+    C0 = fetch(0, a + w, w)
+    np.testing.assert_allclose(C0, Xh.T @ Xh[:, a:], rtol=0, atol=1e-9 * m)
+    Xw1 = Xh[:, a:] - Xh[:, :a] @ C0[:a]
+    G1 = fetch(1, w, w)
+    np.testing.assert_allclose(G1, Xw1.T @ Xw1, rtol=1e-9, atol=1e-9 * np.abs(G1).max())
+    M = fetch(2, w, w)
+    d = np.sqrt(np.diag(G1))
+    R = np.linalg.cholesky(G1 / np.outer(d, d)).T
+    np.testing.assert_allclose(M, np.triu(np.linalg.inv(R) / d[:, None]), rtol=1e-9, atol=1e-12 * np.abs(M).max())
+    np.testing.assert_allclose(fetch(3, w, w), np.eye(w), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(X.to_host()[:, a:], Xw1 @ M, rtol=0, atol=1e-10 * np.abs(Xw1 @ M).max())

@@ -443,3 +443,35 @@ def test_subspace_backend_long_stagnating_run_stays_orthonormal(ctx):
             assert st["second_rounds"] > 100 and st["compress"] > 20
     # the level moves with the position in the restart cycle; the two back ends sit at the same place of the same cycle
     assert res["subspace"] < 5e-3 and 0.5 < res["subspace"] / res["direct"] < 2.0
+
+
+def test_subspace_backend_overlap_on_and_off(oracle, monkeypatch):
+    """The overlapped block orthogonalisation of the coordinate-space back end (second projection round + CholQR on the device behind the
+    host's projected solve) against the same solve with every block waiting for its own orthogonalisation: the same
+    trips, the same residual estimates (to 1e-8 while the trajectories have not drifted apart), the same solution; and it is really taken."""
+    import rails_amd
+    from rails_amd import problems as P
+
+    A = P.laplace7(14, 12, 10)
+    m = A[0].size - 1
+    B = P.rhs(m, 6, seed=5)
+    params = {"Restart size": 90, "Reduced size": 40, "Expand size": 6, "Lanczos iterations": 8, "Tolerance": 1e-7}
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RAILS_SUBSPACE_OVERLAP", mode)
+        c = rails_amd.Context(device=0, seed=1)
+        code, V, T, s = _solve(c, A, B, params, seed=9, options={"subspace": 1})
+        assert code == 0
+        runs[mode] = (s.trips(), np.array(s.history()), V @ T @ V.T, s.backend_stats())
+        s.close()
+        c.close()
+    (t0, h0, X0, st0), (t1, h1, X1, st1) = runs["0"], runs["1"]
+    assert st0["overlapped_blocks"] == 0 and st1["overlapped_blocks"] >= t1 - 2
+    assert t0 == t1
+    # the first trips to rounding level (the prediction is good to ~1e-12); later ones as two free-running trajectories agree
+    np.testing.assert_allclose(h1[:8], h0[:8], rtol=1e-8)
+    np.testing.assert_allclose(h1, h0, rtol=5e-2)
+    assert np.linalg.norm(X1 - X0) <= 10 * params["Tolerance"] * np.linalg.norm(X0)
+    out = oracle.solve(A, B, oracle.params({**params, "rng_mode": 1, "seed": 9}))
+    Xo = out["V"] @ out["T"] @ out["V"].T
+    assert np.linalg.norm(X1 - Xo) <= 10 * params["Tolerance"] * np.linalg.norm(Xo)
