@@ -505,8 +505,9 @@ static bool smith_lyapunov(bool tr, int n, const double *A, int lda, double *X, 
 // shift and pays for spread spectra with squarings of n x n matrices).  Cost: L + 1 LU factorisations, one solve with r right-hand
 // sides per term, X = Z Z', the residual check -- ~12 n^3 flops at n = 200, r = 16 against ~35 n^3.  All terms are positive
 // semi-definite: nothing cancels.  Same fences: verified residual, early exit when the terms do not shrink, false = not applicable.
-static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, double *X, int ldx)
+static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, double *X, int ldx, bool *not_applicable)
 {
+    *not_applicable = false;
     if (!g_lp.dgetrf || !g_lp.dgetrs) return false;
     static const bool trace_lr = getenv("RAILS_SB03MD_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -531,7 +532,10 @@ static bool adi_lyapunov_lowrank(bool tr, int n, const double *A, int lda, doubl
     std::vector<int> piv(n);
     int rank = 0, info = 0;
     rails_dpstrf('U', n, W.data(), n, piv.data(), &rank, 1e-15 * dmax, &info);
-    if (info < 0 || rank <= 0 || rank > n / 3) return false; // not (semi-)definite of low rank: the dense form decides
+    if (info < 0 || rank <= 0 || rank > n / 3) { // not (semi-)definite of low rank: the dense form decides, and nothing is held against this route
+        *not_applicable = true;
+        return false;
+    }
     std::vector<double> F((size_t)n * rank, 0.0); // F(piv[j], i) = R(i, j)
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < rank && i <= j; ++i) F[piv[j] + (size_t)i * n] = W[i + (size_t)j * n];
@@ -798,10 +802,11 @@ extern "C" void rails_sb03md(char dico, char job, char fact, char trans, int n, 
     }();
     int &smith_pause = sb03md_smith_pause();
     int &lowrank_pause = sb03md_factored_pause();
+    bool adi_na = false; // the factored route did not apply (right-hand side not of low rank relative to n): no reason to rest it
     if (use_smith && n >= 32) {
         if (smith_pause > 0)
             --smith_pause;
-        else if ((lowrank_pause > 0 ? (--lowrank_pause, false) : (adi_lyapunov_lowrank(tr, n, A, lda, X, ldx) || (lowrank_pause = 30, false))) ||
+        else if ((lowrank_pause > 0 ? (--lowrank_pause, false) : (adi_lyapunov_lowrank(tr, n, A, lda, X, ldx, &adi_na) || (lowrank_pause = adi_na ? 0 : 30, false))) ||
                  smith_lyapunov(tr, n, A, lda, X, ldx)) {
             g_sb03md_smith++;
             *scale = 1.0;
