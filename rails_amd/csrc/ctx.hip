@@ -72,6 +72,7 @@ extern "C" int rails_ctx_destroy(rails_ctx *c)
     rails_stream_sync(c);
     rails_lanczos_release(c);
     rails_rccl_release(c);
+    rails_library_gemm_release(c);
     for (auto &fp : c->free_panels) hipFree(fp.second);
     c->free_panels.clear();
     if (c->ws) hipFree(c->ws);

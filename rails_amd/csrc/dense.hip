@@ -15,6 +15,9 @@
 // over the ranks through the context hook.
 #include "rails_internal.h"
 
+#include <dlfcn.h>
+#include <mutex>
+
 #include <algorithm>
 
 namespace {
@@ -558,6 +561,68 @@ int rails_panel_gemm_dev(rails_ctx *c, double alpha, const double *X, int ldx, i
     return RAILS_OK;
 }
 
+// ---- the plain wide GEMM of a basis rotation through rocBLAS -----------------------------------------------------------------------
+// P2 = P Q with m = 1M rows, k and r in the hundreds, is a plain DGEMM, compute-bound: rocBLAS runs it at 44 TFLOP/s where
+// k_panel_gemm<8, 32> (built around the bandwidth-bound narrow shapes) reaches 30 -- 3.9 instead of 5.8 ms per restart at k = 324,
+// r = 268.  librocblas is resolved with dlopen (a library GEMM is what the platform's BLAS is for; everything else in this file is
+// hand-written); creating the handle takes 0.3 s, so a solver that is going to rotate asks for it up front
+// (rails_ctx_enable_library_gemm), not in the middle of a solve.  RAILS_WIDE_GEMM=own keeps the hand-written kernel.
+namespace {
+struct RocblasApi {
+    void *handle = nullptr;
+    int (*create)(void **) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    int (*set_stream)(void *, hipStream_t) = nullptr;
+    int (*dgemm)(void *, int, int, int, int, int, const double *, const double *, int, const double *, int, const double *, double *, int) = nullptr;
+    bool tried = false, ok = false;
+};
+RocblasApi g_rocblas;
+std::mutex g_rocblas_mutex;
+
+bool load_rocblas()
+{
+    std::lock_guard<std::mutex> lock(g_rocblas_mutex);
+    if (g_rocblas.tried) return g_rocblas.ok;
+    g_rocblas.tried = true;
+    if (const char *e = getenv("RAILS_WIDE_GEMM"))
+        if (!strcmp(e, "own")) return false;
+    const char *names[] = {getenv("RAILS_ROCBLAS_LIB"), "librocblas.so", "/opt/rocm/lib/librocblas.so", "librocblas.so.5", "librocblas.so.4"};
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        if ((g_rocblas.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    }
+    if (!g_rocblas.handle) return false;
+    g_rocblas.create = (int (*)(void **))dlsym(g_rocblas.handle, "rocblas_create_handle");
+    g_rocblas.destroy = (int (*)(void *))dlsym(g_rocblas.handle, "rocblas_destroy_handle");
+    g_rocblas.set_stream = (int (*)(void *, hipStream_t))dlsym(g_rocblas.handle, "rocblas_set_stream");
+    g_rocblas.dgemm = (decltype(g_rocblas.dgemm))dlsym(g_rocblas.handle, "rocblas_dgemm");
+    g_rocblas.ok = g_rocblas.create && g_rocblas.destroy && g_rocblas.set_stream && g_rocblas.dgemm;
+    return g_rocblas.ok;
+}
+constexpr int ROCBLAS_OP_N = 111, ROCBLAS_OP_T = 112;
+} // namespace
+
+extern "C" int rails_ctx_enable_library_gemm(rails_ctx *c)
+{
+    RAILS_REQUIRE(c, "rails_ctx_enable_library_gemm: null context");
+    if (c->rocblas || !load_rocblas()) return RAILS_OK; // without the library the hand-written kernel does the work
+    hipSetDevice(c->device);
+    void *h = nullptr;
+    if (g_rocblas.create(&h) != 0 || !h) return RAILS_OK;
+    if (g_rocblas.set_stream(h, c->stream) != 0) {
+        g_rocblas.destroy(h);
+        return RAILS_OK;
+    }
+    c->rocblas = h;
+    return RAILS_OK;
+}
+
+void rails_library_gemm_release(rails_ctx *c)
+{
+    if (c->rocblas && g_rocblas.destroy) g_rocblas.destroy(c->rocblas);
+    c->rocblas = nullptr;
+}
+
 // Y[:, yc0:yc0+r] = beta * Y + alpha * X[:, xc0:xc0+k] * C for any r: C goes to the device in ONE upload and the product is launched in
 // slices of 128 output columns (the faster tile shape) without the host waiting in between -- rails_panel_gemm re-uses one staging
 // buffer per call, so a loop over it makes the host wait for every slice's kernel but the last (the basis rotation P <- P Q of the
@@ -585,6 +650,14 @@ extern "C" int rails_panel_gemm_wide(rails_ctx *c, double alpha, const rails_pan
     for (int j = 0; j < r; ++j) memcpy(c->pinned + (size_t)j * k, C_host + (size_t)j * ldc, sizeof(double) * k);
     RAILS_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     RAILS_TRY(rails_pinned_end_write(c));
+    if (c->rocblas && k >= 64 && r >= 64 && X->m < 0x7fffffffLL) {
+        // row-major panels are column-major matrices transposed: Y' (r x m, ld) = alpha C' (r x k) X' (k x m, ld) + beta Y'
+        const int m32 = (int)X->m;
+        const int rc = g_rocblas.dgemm(c->rocblas, ROCBLAS_OP_T, ROCBLAS_OP_N, r, m32, k, &alpha, c->small, k, X->d + xc0, X->ld, &beta, Y->d + yc0, Y->ld);
+        if (rc == 0) return RAILS_OK;
+        rails_set_error("rails_panel_gemm_wide: rocblas_dgemm failed with status %d", rc);
+        return RAILS_EHIP;
+    }
     for (int j0 = 0; j0 < r; j0 += 128) {
         const int nc = std::min(128, r - j0);
         RAILS_TRY(rails_panel_gemm_dev(c, alpha, X->d + xc0, X->ld, k, c->small + (size_t)j0 * k, nc, beta, Y->d + yc0 + j0, Y->ld, X->m));

@@ -56,6 +56,7 @@ struct rails_ctx {
     rails_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
     // RCCL communicator over the ranks of the partition (rccl_comm.hip); used when no hook is installed
+    void *rocblas = nullptr; // rocblas_handle for the plain wide GEMM of a basis rotation (dense.hip: rails_ctx_enable_library_gemm)
     void *rccl = nullptr;
     bool own_rccl = false;
     int rccl_nranks = 0, rccl_rank = 0;
@@ -218,6 +219,7 @@ struct rails_slow_guard {
 
 // ---- helpers implemented in ctx.hip ----
 int rails_ws_reserve(rails_ctx *ctx, size_t bytes);
+void rails_library_gemm_release(rails_ctx *ctx);
 int rails_small_reserve(rails_ctx *ctx, size_t bytes);
 int rails_pinned_reserve(rails_ctx *ctx, size_t bytes);
 // host -> pinned -> device staging without a stream synchronisation: begin_write waits until the previous upload out of the

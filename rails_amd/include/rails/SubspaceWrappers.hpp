@@ -121,9 +121,22 @@ public:
     {
         const size_t cap = (size_t)P.capacity();
         hip_ok(rails_ctx_reserve_staging(ctx, cap * cap / 2 * sizeof(double)), "rails_ctx_reserve_staging"); // the rotation's Q, Gram results
+        hip_ok(rails_ctx_enable_library_gemm(ctx), "rails_ctx_enable_library_gemm"); // the rotation is a plain wide GEMM: the platform's BLAS (0.3 s to set up, here)
         if (P2.N() >= 0 && P2.capacity() >= P.capacity()) return;
         P2 = HipMultiVectorWrapper(m_local, P.capacity(), ctx);
         P2.set_global_rows(m_global);
+        // one rotation-shaped product now (zero coefficients: P2 is scratch until the first compress()): whatever the GEMM path loads
+        // or selects on its first call, it does here and not at the first restart of a solve
+        const int kw = std::min(256, (int)P.capacity());
+        if (kw >= 64) {
+            std::vector<double> Z((size_t)kw * kw, 0.0);
+            const int keep = P.N();
+            P.resize(kw);
+            P2.resize(kw);
+            hip_ok(rails_panel_fill(ctx, P.panel(), keep, kw - keep, 0.0), "rails_panel_fill");
+            hip_ok(rails_panel_gemm_wide(ctx, 1.0, P.panel(), 0, kw, Z.data(), kw, kw, 0.0, P2.panel(), 0), "rails_panel_gemm_wide");
+            P.resize(keep);
+        }
         P2.resize(0);
     }
 
