@@ -163,6 +163,7 @@ def main():
     assert stream, "expected a non-default stream handle"
     ctx = rails_amd.Context(device=local_rank, stream=stream, seed=args.seed)
     ctx.set_partition(rank, nranks, r0, mg)
+    ctx.enable_library_gemm()  # set-up: the basis rotation of restarts goes through rocBLAS (creating its handle takes 0.3 s, once)
     collectives = "none (single GPU)"
     if nranks > 1:
         starts = np.arange(nranks + 1, dtype=np.int64) * ml

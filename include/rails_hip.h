@@ -210,11 +210,13 @@ int rails_gram(rails_ctx *ctx, const rails_panel *X, int xc0, int a, const rails
 int rails_panel_gemm(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int k, const double *C_host,
                      int ldc, int r, double beta, rails_panel *Y, int yc0);
 
-/* Ask for the platform's BLAS (rocBLAS, resolved with dlopen) for the one plain wide GEMM of the library: rails_panel_gemm_wide with
- * k, r >= 64 (the basis rotation of the coordinate-space back end, compute-bound: 44 instead of 30 TFLOP/s).  Creating the handle
- * takes ~0.3 s: call it when a solver is set up, not inside a solve.  Without the library (or with RAILS_WIDE_GEMM=own) nothing
- * changes: the hand-written kernel does the work. */
+/* The platform's BLAS (rocBLAS, resolved with dlopen) for the one plain wide GEMM of the library: rails_panel_gemm_wide with
+ * k, r >= 64 (the basis rotation of the coordinate-space back end, compute-bound: 44 instead of 30 TFLOP/s).  Creating its handle takes
+ * ~0.3 s (once per process, for the calling context's device): call this when the process sets up; the coordinate-space back end
+ * calls it by itself at the second restart a process sees.  Until then -- rails_ctx_library_gemm_ready -- or without the library
+ * (or with RAILS_WIDE_GEMM=own) the hand-written kernel does the work. */
 int rails_ctx_enable_library_gemm(rails_ctx *ctx);
+int rails_ctx_library_gemm_ready(const rails_ctx *ctx);
 
 /* Deferred small results: a chain Gram -> update -> Gram -> Cholesky -> update on the device without the host in between (the block
  * orthogonalisation of the coordinate-space back end behind the host's projected solve).  An arena of `nslots` slots of

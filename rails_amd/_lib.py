@@ -30,6 +30,7 @@ SIGNATURES = {
     "rails_ctx_stream": (_vp, [_vp]),
     "rails_ctx_set_meter": (C.c_int, [_vp, C.c_int]),
     "rails_ctx_enable_library_gemm": (C.c_int, [_vp]),
+    "rails_ctx_library_gemm_ready": (C.c_int, [_vp]),
     "rails_deferred_reserve": (C.c_int, [_vp, C.c_int, C.c_int64]),
     "rails_gram_deferred": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
     "rails_panel_gemm_deferred": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int]),

@@ -16,6 +16,7 @@
 #include "rails_internal.h"
 
 #include <dlfcn.h>
+#include <atomic>
 #include <mutex>
 
 #include <algorithm>
@@ -602,26 +603,40 @@ bool load_rocblas()
 constexpr int ROCBLAS_OP_N = 111, ROCBLAS_OP_T = 112;
 } // namespace
 
+// One handle per process (for the device of the first context that asks).  rocblas_create_handle takes 0.3 s and is NOT done behind the
+// caller's back on another thread (tried: a native program that starts using the GPU at once crashed now and then while rocBLAS was
+// loading its code objects): whoever wants the library path asks for it at a convenient moment -- bench.py when it sets up, the
+// coordinate-space back end at the second restart a process sees (by then the process is a long-running one).
+namespace {
+struct LibraryGemm {
+    std::atomic<int> state{0}; // 0 not asked for, 2 ready, 3 not available
+    int device = -1;
+    void *handle = nullptr;
+    std::mutex use; // creation; set_stream + dgemm of one caller at a time
+};
+LibraryGemm g_libgemm;
+} // namespace
+
 extern "C" int rails_ctx_enable_library_gemm(rails_ctx *c)
 {
     RAILS_REQUIRE(c, "rails_ctx_enable_library_gemm: null context");
-    if (c->rocblas || !load_rocblas()) return RAILS_OK; // without the library the hand-written kernel does the work
-    hipSetDevice(c->device);
+    std::lock_guard<std::mutex> lock(g_libgemm.use);
+    if (g_libgemm.state.load() != 0) return RAILS_OK;
+    g_libgemm.device = c->device;
     void *h = nullptr;
-    if (g_rocblas.create(&h) != 0 || !h) return RAILS_OK;
-    if (g_rocblas.set_stream(h, c->stream) != 0) {
-        g_rocblas.destroy(h);
-        return RAILS_OK;
+    if (!load_rocblas() || hipSetDevice(c->device) != hipSuccess || g_rocblas.create(&h) != 0 || !h) {
+        g_libgemm.state = 3;
+        return RAILS_OK; // without the library the hand-written kernel does the work
     }
-    c->rocblas = h;
+    g_libgemm.handle = h;
+    g_libgemm.state = 2;
     return RAILS_OK;
 }
 
-void rails_library_gemm_release(rails_ctx *c)
-{
-    if (c->rocblas && g_rocblas.destroy) g_rocblas.destroy(c->rocblas);
-    c->rocblas = nullptr;
-}
+// 1 when rails_panel_gemm_wide on this context goes through the library from now on
+extern "C" int rails_ctx_library_gemm_ready(const rails_ctx *c) { return c && g_libgemm.state.load() == 2 && g_libgemm.device == c->device ? 1 : 0; }
+
+void rails_library_gemm_release(rails_ctx *) {}
 
 // Y[:, yc0:yc0+r] = beta * Y + alpha * X[:, xc0:xc0+k] * C for any r: C goes to the device in ONE upload and the product is launched in
 // slices of 128 output columns (the faster tile shape) without the host waiting in between -- rails_panel_gemm re-uses one staging
@@ -650,10 +665,12 @@ extern "C" int rails_panel_gemm_wide(rails_ctx *c, double alpha, const rails_pan
     for (int j = 0; j < r; ++j) memcpy(c->pinned + (size_t)j * k, C_host + (size_t)j * ldc, sizeof(double) * k);
     RAILS_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     RAILS_TRY(rails_pinned_end_write(c));
-    if (c->rocblas && k >= 64 && r >= 64 && X->m < 0x7fffffffLL) {
+    if (k >= 64 && r >= 64 && X->m < 0x7fffffffLL && rails_ctx_library_gemm_ready(c)) {
         // row-major panels are column-major matrices transposed: Y' (r x m, ld) = alpha C' (r x k) X' (k x m, ld) + beta Y'
         const int m32 = (int)X->m;
-        const int rc = g_rocblas.dgemm(c->rocblas, ROCBLAS_OP_T, ROCBLAS_OP_N, r, m32, k, &alpha, c->small, k, X->d + xc0, X->ld, &beta, Y->d + yc0, Y->ld);
+        std::lock_guard<std::mutex> lock(g_libgemm.use);
+        int rc = g_rocblas.set_stream(g_libgemm.handle, c->stream);
+        if (rc == 0) rc = g_rocblas.dgemm(g_libgemm.handle, ROCBLAS_OP_T, ROCBLAS_OP_N, r, m32, k, &alpha, c->small, k, X->d + xc0, X->ld, &beta, Y->d + yc0, Y->ld);
         if (rc == 0) return RAILS_OK;
         rails_set_error("rails_panel_gemm_wide: rocblas_dgemm failed with status %d", rc);
         return RAILS_EHIP;

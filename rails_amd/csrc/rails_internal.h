@@ -56,7 +56,6 @@ struct rails_ctx {
     rails_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
     // RCCL communicator over the ranks of the partition (rccl_comm.hip); used when no hook is installed
-    void *rocblas = nullptr; // rocblas_handle for the plain wide GEMM of a basis rotation (dense.hip: rails_ctx_enable_library_gemm)
     void *rccl = nullptr;
     bool own_rccl = false;
     int rccl_nranks = 0, rccl_rank = 0;

@@ -22,6 +22,7 @@
 #define RAILS_SUBSPACEWRAPPERS_HPP
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -121,14 +122,13 @@ public:
     {
         const size_t cap = (size_t)P.capacity();
         hip_ok(rails_ctx_reserve_staging(ctx, cap * cap / 2 * sizeof(double)), "rails_ctx_reserve_staging"); // the rotation's Q, Gram results
-        hip_ok(rails_ctx_enable_library_gemm(ctx), "rails_ctx_enable_library_gemm"); // the rotation is a plain wide GEMM: the platform's BLAS (0.3 s to set up, here)
         if (P2.N() >= 0 && P2.capacity() >= P.capacity()) return;
         P2 = HipMultiVectorWrapper(m_local, P.capacity(), ctx);
         P2.set_global_rows(m_global);
         // one rotation-shaped product now (zero coefficients: P2 is scratch until the first compress()): whatever the GEMM path loads
         // or selects on its first call, it does here and not at the first restart of a solve
         const int kw = std::min(256, (int)P.capacity());
-        if (kw >= 64) {
+        if (kw >= 64 && rails_ctx_library_gemm_ready(ctx)) { // (the hand-written kernels are loaded with the library)
             std::vector<double> Z((size_t)kw * kw, 0.0);
             const int keep = P.N();
             P.resize(kw);
@@ -390,6 +390,10 @@ public:
     void compress()
     {
         if (!resolve_pending()) return;
+        // the rotation below is a plain wide GEMM: from the second restart a process sees it goes through the platform's BLAS (0.3 s to
+        // set up, once: a process that restarts twice is going to be around for a while; bench.py asks for it when it sets up)
+        static std::atomic<int> restarts_seen{0};
+        if (++restarts_seen == 2) hip_ok(rails_ctx_enable_library_gemm(ctx), "rails_ctx_enable_library_gemm");
         std::vector<std::shared_ptr<CoefStore>> stores;
         std::vector<std::weak_ptr<CoefStore>> still;
         int ncols = 0;

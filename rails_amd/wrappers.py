@@ -94,6 +94,10 @@ class Context:
         check(self.lib.rails_ctx_stats(self.h, buf, 1024), "rails_ctx_stats")
         return json.loads(buf.value.decode())
 
+    def enable_library_gemm(self):
+        """set up the platform's BLAS for the basis rotation of restarts now (0.3 s, once per process) rather than at the second restart"""
+        check(self.lib.rails_ctx_enable_library_gemm(self.h), "rails_ctx_enable_library_gemm")
+
     def set_meter(self, on=True):
         """device-busy meter: stats()["gpu_busy_ms"] adds up the time the GPU worked for this context"""
         check(self.lib.rails_ctx_set_meter(self.h, 1 if on else 0), "rails_ctx_set_meter")
