@@ -210,6 +210,7 @@ def main():
             X.random()
             for variant in ((1, 2, 7) if args.spmm_variant == 0 else (args.spmm_variant,)):
                 A.set_variant(variant)
+                A.prepare(kk)
                 try:
                     for _ in range(3):
                         A.apply(X, Y)
@@ -232,6 +233,9 @@ def main():
     X = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk)
     Y = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk)
     X.random()
+    t_prep = time.time()
+    A.prepare(kk)  # set-up for repeated products of this width (the sweep kernel's schedule on banded patterns; untimed, like the CSR upload)
+    log("[rank %d] prepare(%d) %.2fs" % (rank, kk, time.time() - t_prep))
     for _ in range(3):
         A.apply(X, Y)
     ctx.sync()

@@ -147,7 +147,14 @@ int rails_spmm(rails_ctx *ctx, rails_csr *A, int trans, const rails_panel *X, in
  * 7 = sweep kernel (banded patterns: X streamed once per XCD through LDS rings, partial sums in registers; fails when the
  * pattern or the column count does not fit), 8 = never the sweep kernel (auto otherwise). */
 int rails_csr_set_variant(rails_csr *A, int variant);
-/* Statistics of the sweep kernel's schedule for nc columns, once a product of that width has built it:
+/* Set-up for products of nc columns with A (trans != 0: with its transpose): builds now what the automatic kernel choice would
+ * otherwise put off -- the sweep kernel's schedule (banded patterns, 64 to 256 columns) costs about a second of host time per million
+ * rows, a thousand times what it saves one product, so without this call an operator only builds it after it has been asked for
+ * RAILS_SWEEP_AFTER (default 16) products of that width.  *kernel_ready (may be null) = 1 when the sweep kernel will take them.  A
+ * no-op for operators and widths the kernel does not apply to.  The reference has no counterpart: Epetra's FillComplete is the
+ * nearest (set-up work of the matrix class before `A_ * W`, src/LyapunovSolver.hpp:146). */
+int rails_csr_prepare(rails_ctx *ctx, rails_csr *A, int trans, int nc, int *kernel_ready);
+/* Statistics of the sweep kernel's schedule for nc columns, once it has been built:
  * out[0] slot efficiency, [1] X rows staged per matrix row and chunk, [2] lock-step trips, [3] 1 if the schedule exists. */
 int rails_csr_sweep_stats(rails_csr *A, int nc, double *out);
 /* A rectangular operator, n_rows x n_cols, all columns local: in rails_spmm X has n_cols rows and Y n_rows; no transposed apply, no

@@ -56,6 +56,7 @@ SIGNATURES = {
     "rails_spmm": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int]),
     "rails_csr_set_variant": (C.c_int, [_vp, C.c_int]),
     "rails_csr_sweep_stats": (C.c_int, [_vp, C.c_int, _dp]),
+    "rails_csr_prepare": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rails_csr_last_kernel": (C.c_char_p, [_vp]),
     "rails_sweep_plan_create": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, _dp, _ip, C.POINTER(_vp)]),
     "rails_sweep_plan_destroy": (C.c_int, [_vp]),

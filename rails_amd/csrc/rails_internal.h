@@ -236,6 +236,7 @@ void rails_rccl_release(rails_ctx *c);
 // spmm_sweep.hip: the sweep kernel for banded patterns; *done tells whether it computed the product
 int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool aligned,
                      bool force, bool *done);
+int rails_sweep_prepare(rails_ctx *c, rails_csr *A, int nc, bool *fits); // the schedule for nc columns, now
 void rails_sweep_release(rails_csr *A);
 // dense.hip: partial Gram into device memory (no host copy / all-reduce): C_dev (a x b col-major, ldc = a)
 int rails_gram_dev(rails_ctx *ctx, const double *X, int ldx, const double *Y, int ldy, int64_t m, int a, int b,

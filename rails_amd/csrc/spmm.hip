@@ -470,6 +470,40 @@ int rails_spmm_tiled(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
 
 static bool rails_csr_is_grid(rails_csr *A); // structured-grid stencil (the LDS-staged box kernel's territory), looked at once
 
+// The sweep kernel as the automatic choice, from what is known without building its schedule: 64 to 256 columns in chunks of 16 that
+// divide the 32 workgroups of an XCD; the window of columns of a row fits (phases - 1) blocks of 2816 rows (the planner decides
+// exactly); every XCD's part holds a few blocks per phase; an X row is staged by at most 8 workgroups per row of the part (phases x
+// (1 + window / rows of a part): the launcher's own bound); and the pattern is not a structured-grid stencil -- few nonzeros per row
+// leave the sweep at its floor of one LDS-DMA latency per step and the LDS-staged box kernel is faster (7-point Laplacian 50 x 50 x
+// 400 at 128 columns: 0.65 ms against 0.82).
+static bool sweep_worthwhile(rails_csr *A, int nc)
+{
+    if (!(nc >= 64 && nc <= 256 && nc % 16 == 0 && 32 % (nc / 16) == 0 && A->n_ghost == 0 && A->window_rows > 0)) return false;
+    const int64_t phases = 32 / (nc / 16), part_rows = A->m / 8;
+    if (!(A->window_rows + 256 <= (phases - 1) * 2816 && A->m >= 8 * phases * 2816 &&
+          (double)phases * (double)(part_rows + A->window_rows + 1024) <= 8.0 * (double)part_rows))
+        return false;
+    return !rails_csr_is_grid(A);
+}
+
+extern "C" int rails_csr_prepare(rails_ctx *c, rails_csr *A, int trans, int nc, int *kernel_ready)
+{
+    RAILS_REQUIRE(c && A && nc >= 1, "rails_csr_prepare: bad argument");
+    if (kernel_ready) *kernel_ready = 0;
+    if (A->apply_cb) return RAILS_OK;
+    if (trans) {
+        RAILS_TRY(build_transpose(A));
+        A->AT->variant = A->variant;
+        return rails_csr_prepare(c, A->AT, 0, nc, kernel_ready);
+    }
+    if (A->variant == 7 || (A->variant == 0 && sweep_worthwhile(A, nc))) {
+        bool fits = false;
+        RAILS_TRY(rails_sweep_prepare(c, A, nc, &fits));
+        if (kernel_ready) *kernel_ready = fits ? 1 : 0;
+    }
+    return RAILS_OK;
+}
+
 extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_panel *X, int xc0, int nc, rails_panel *Y, int yc0)
 {
     if (c) hipSetDevice(c->device); // allocations and launches go to the context's device whatever the caller's current device is
@@ -546,15 +580,7 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     // a second per million rows): 64 to 256 columns in chunks of 16 that divide the 32 workgroups of an XCD; the window of columns of a
     // row fits (phases - 1) blocks of 2816 rows (the planner decides exactly); every XCD's part holds a few blocks per phase; and an X
     // row is staged by at most 8 workgroups per row of the part (phases x (1 + window / rows of a part): the launcher's own bound).
-    bool sweep_auto = false;
-    if (A->variant == 0 && nc >= 64 && nc <= 256 && nc % 16 == 0 && 32 % (nc / 16) == 0 && A->n_ghost == 0 && A->window_rows > 0) {
-        const int64_t phases = 32 / (nc / 16), part_rows = A->m / 8;
-        sweep_auto = A->window_rows + 256 <= (phases - 1) * 2816 && A->m >= 8 * phases * 2816 &&
-                     (double)phases * (double)(part_rows + A->window_rows + 1024) <= 8.0 * (double)part_rows;
-        // structured-grid stencils stay with the LDS-staged box kernel: few nonzeros per row leave the sweep at its floor of one LDS-DMA
-        // latency per step (7-point Laplacian 50 x 50 x 400 at 128 columns: 0.65 ms against 0.82)
-        if (sweep_auto && rails_csr_is_grid(A)) sweep_auto = false;
-    }
+    const bool sweep_auto = A->variant == 0 && sweep_worthwhile(A, nc);
     if (A->variant == 7 || sweep_auto) {
         const bool al = ((xc0 | yc0) & 1) == 0 && X->ld % 2 == 0 && Y->ld % 2 == 0 && ldg % 2 == 0;
         RAILS_TRY(rails_spmm_sweep(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, al, A->variant == 7, &done));

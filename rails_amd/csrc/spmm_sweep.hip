@@ -212,6 +212,7 @@ void free_plan(DevPlan *d)
 // plans of an operator, one per number of column chunks (kept in rails_csr::sweep_plans as an opaque pointer)
 struct rails_sweep_cache {
     std::map<int, DevPlan *> by_chunks;
+    std::map<int, int> asked; // products of that width seen in automatic mode before the schedule exists
 };
 
 void rails_sweep_release(rails_csr *A)
@@ -225,18 +226,9 @@ void rails_sweep_release(rails_csr *A)
 // the geometry the kernel is instantiated for
 static constexpr int SWEEP_W = 8, SWEEP_G = 22;
 
-// *done = true when the product was computed here.  force: fail instead of declining.
-int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool aligned,
-                     bool force, bool *done)
+// The schedule of A for n_chunks column chunks, built (host, a second per million rows) and copied to the device when missing.
+static int ensure_plan(rails_ctx *c, rails_csr *A, int n_chunks, DevPlan **out)
 {
-    *done = false;
-    const int n_chunks = nc / 16;
-    const bool shape_ok = aligned && nc % 16 == 0 && n_chunks >= 1 && n_chunks <= 32 && 32 % n_chunks == 0 && c->num_cu >= 256 && A->n_ghost == 0 &&
-                          A->ncols_ext < 0x7fffffffLL;
-    if (!shape_ok) {
-        RAILS_REQUIRE(!force, "rails_spmm: the sweep kernel needs a multiple of 16 columns that divides 512, even column offsets, 256 CUs and no ghost rows");
-        return RAILS_OK;
-    }
     if (!A->sweep) A->sweep = new rails_sweep_cache();
     DevPlan *&d = A->sweep->by_chunks[n_chunks];
     if (!d) {
@@ -269,6 +261,48 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
             d->ok = true;
         }
     }
+    *out = d;
+    return RAILS_OK;
+}
+
+static bool sweep_shape_ok(const rails_ctx *c, const rails_csr *A, int nc, bool aligned)
+{
+    const int n_chunks = nc / 16;
+    return aligned && nc % 16 == 0 && n_chunks >= 1 && n_chunks <= 32 && 32 % n_chunks == 0 && c->num_cu >= 256 && A->n_ghost == 0 &&
+           A->ncols_ext < 0x7fffffffLL;
+}
+
+// Builds the schedule for nc columns ahead of the products (rails_csr_prepare): *fits says whether the kernel will take them.
+int rails_sweep_prepare(rails_ctx *c, rails_csr *A, int nc, bool *fits)
+{
+    *fits = false;
+    if (!sweep_shape_ok(c, A, nc, true)) return RAILS_OK;
+    DevPlan *d = nullptr;
+    RAILS_TRY(ensure_plan(c, A, nc / 16, &d));
+    *fits = d->ok && d->host.efficiency >= 0.4 && d->host.staged_rows_per_row <= 8.0;
+    return RAILS_OK;
+}
+
+// *done = true when the product was computed here.  force: fail instead of declining.  In automatic mode (!force) the schedule is not
+// built by the first product that could use it: it costs about a thousand products' worth of the time it saves each of them, so the
+// operator waits until it has been asked for RAILS_SWEEP_AFTER (16) products of that width -- a sign of a caller that streams panels
+// through A -- or until rails_csr_prepare says so.
+int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool aligned,
+                     bool force, bool *done)
+{
+    *done = false;
+    const int n_chunks = nc / 16;
+    if (!sweep_shape_ok(c, A, nc, aligned)) {
+        RAILS_REQUIRE(!force, "rails_spmm: the sweep kernel needs a multiple of 16 columns that divides 512, even column offsets, 256 CUs and no ghost rows");
+        return RAILS_OK;
+    }
+    if (!A->sweep) A->sweep = new rails_sweep_cache();
+    if (!force && !A->sweep->by_chunks.count(n_chunks)) {
+        static const int after = getenv("RAILS_SWEEP_AFTER") ? atoi(getenv("RAILS_SWEEP_AFTER")) : 16;
+        if (++A->sweep->asked[n_chunks] < after) return RAILS_OK;
+    }
+    DevPlan *d = nullptr;
+    RAILS_TRY(ensure_plan(c, A, n_chunks, &d));
     if (!d->ok) {
         RAILS_REQUIRE(!force, "rails_spmm: the sweep kernel does not fit this operator: %s", d->host.why.c_str());
         return RAILS_OK;

@@ -532,6 +532,15 @@ public:
         return out;
     }
 
+    // Set-up for many products with panels of nc columns (rails_csr_prepare: the sweep kernel's schedule on banded patterns, which an
+    // operator would otherwise only build after its 16th such product).  True when that kernel will take them.  No reference counterpart.
+    bool prepare(int nc) const
+    {
+        int ready = 0;
+        if (!h_ || !hip_ok(rails_csr_prepare(ctx_, h_->A, transpose_ ? 1 : 0, nc, &ready), "rails_csr_prepare")) return false;
+        return ready != 0;
+    }
+
 private:
     static int trampoline(void *user, int trans, const rails_panel *X, int xc0, int nc, rails_panel *Y, int yc0)
     {

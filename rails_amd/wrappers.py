@@ -392,8 +392,15 @@ class HipOperatorWrapper:
     def last_kernel(self):
         return self.ctx.lib.rails_csr_last_kernel(self.h.h).decode()
 
+    def prepare(self, nc):
+        """Set-up for many products of nc columns (rails_csr_prepare): builds the sweep kernel's schedule now where it applies instead of
+        after the 16th such product.  Returns True when the sweep kernel will take them."""
+        ready = C.c_int(0)
+        check(self.ctx.lib.rails_csr_prepare(self.ctx.h, self.h.h, 1 if self.trans else 0, nc, C.byref(ready)), "rails_csr_prepare")
+        return bool(ready.value)
+
     def sweep_stats(self, nc):
-        """Schedule statistics of the sweep kernel for nc columns (zeros until a product of that width has built the schedule)."""
+        """Schedule statistics of the sweep kernel for nc columns (zeros until the schedule exists: prepare(), or the 16th product)."""
         out = (C.c_double * 4)()
         check(self.ctx.lib.rails_csr_sweep_stats(self.h.h, nc, out), "rails_csr_sweep_stats")
         return {"efficiency": out[0], "staged_rows_per_row": out[1], "trips": int(out[2]), "built": bool(out[3])}

@@ -61,6 +61,7 @@ def test_spmm_full_size(ctx, oracle, c3):
     # (2) 128 columns (the headline SpMM): sampled rows against a host evaluation of the same rows
     X = MV(ctx, m=m, n=128)
     X.random()
+    assert op.prepare(128)  # set-up for repeated products of this width (rails_csr_prepare): the sweep kernel's schedule
     Y = op.apply(X)
     assert op.last_kernel() == "k_spmm_sweep"  # banded pattern at panel width: the sweep kernel (spmm_sweep.hip) is the automatic choice
     Xh = X.to_host()

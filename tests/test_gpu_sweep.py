@@ -147,7 +147,7 @@ def test_sweep_declines_what_it_cannot_do(ctx):
 
 
 def test_auto_choice_on_the_bench_matrix_and_its_transpose(ctx):
-    """BASELINE configs[2] at full size: auto picks the sweep kernel at 128 columns; linearity and the adjoint identity hold."""
+    """BASELINE configs[2] at full size: after prepare(128) auto picks the sweep kernel at 128 columns; linearity and the adjoint identity hold."""
     import rails_amd
     from rails_amd import problems as P
 
@@ -158,8 +158,17 @@ def test_auto_choice_on_the_bench_matrix_and_its_transpose(ctx):
     Z = rails_amd.HipMultiVectorWrapper(ctx, m=m, n=128, capacity=128)
     X.random()
     Z.random()
+    # without set-up the first products of a width stay with the row kernels: the schedule costs a thousand products' worth of what it saves
+    # (RAILS_SWEEP_AFTER = 16 products of the width, or rails_csr_prepare -- used for the transpose below and in test_gpu_fullsize.py)
+    Y0 = op.apply(X)
+    for _ in range(14):
+        op.apply(X, Y0)
+    assert op.last_kernel() != "k_spmm_sweep" and not op.sweep_stats(128)["built"]
     Y = op.apply(X)
-    assert op.last_kernel() == "k_spmm_sweep"
+    assert op.last_kernel() == "k_spmm_sweep" and op.sweep_stats(128)["built"]
+    d0 = Y.copy()
+    d0 -= Y0
+    assert d0.norm() <= 1e-13 * Y.norm()
     op.set_variant(3)
     Yr = op.apply(X)
     d = Y.copy()
@@ -174,7 +183,10 @@ def test_auto_choice_on_the_bench_matrix_and_its_transpose(ctx):
     assert np.abs(rs - np.add.reduceat(val, rp[:-1])[:, None]).max() < 1e-12
     # adjoint identity <Z, A X> = <A^T Z, X> through the transposed operator (its own schedule)
     lhs = Z.dot(Y)
-    AtZ = op.transpose().apply(Z)
+    At = op.transpose()
+    assert At.prepare(128)
+    AtZ = At.apply(Z)
+    assert op.last_kernel() == "k_spmm_sweep"
     rhs = AtZ.dot(X)
     assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(lhs).max()
 
