@@ -237,6 +237,12 @@ int rails_gram_deferred(rails_ctx *ctx, const rails_panel *X, int xc0, int a, co
 int rails_panel_gemm_deferred(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int k, int slot, int ld, int r, double beta,
                               rails_panel *Y, int yc0);
 int rails_chol_inverse_deferred(rails_ctx *ctx, int slot_in, int w, int slot_out);
+/* First update and second projection of a block in one pass over the basis (the second sweep of the reference's block
+ * Gram-Schmidt, src/StlWrapper.cpp:314-344): Y[:, yc0:yc0+r] += alpha X[:, xc0:xc0+k] C with C on the host (k x r, leading dimension
+ * ldc), then slot <- X[:, xc0:xc0+k]' Y[:, yc0:yc0+r2] for the leading r2 <= r updated columns (k x r2, leading dimension k, summed
+ * over the ranks, on its way to the mirror).  Fused for r <= 17, r2 <= 16, 32 <= k <= 512; the two separate kernels otherwise. */
+int rails_update_gram_deferred(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc, int r,
+                               rails_panel *Y, int yc0, int r2, int slot);
 int rails_deferred_fetch(rails_ctx *ctx, int slot, int64_t n, double *host_out);
 
 /* The same product for any number r of output columns: one upload of C, launches in slices of 128 columns with no host wait in

@@ -33,6 +33,7 @@ SIGNATURES = {
     "rails_ctx_library_gemm_ready": (C.c_int, [_vp]),
     "rails_deferred_reserve": (C.c_int, [_vp, C.c_int, C.c_int64]),
     "rails_gram_deferred": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
+    "rails_update_gram_deferred": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
     "rails_panel_gemm_deferred": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int]),
     "rails_chol_inverse_deferred": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "rails_deferred_fetch": (C.c_int, [_vp, C.c_int, C.c_int64, _dp]),

@@ -416,41 +416,45 @@ __global__ void k_compact_cols(const double *__restrict__ src, int ld, int k, in
 }
 
 // G (w x w, symmetric positive definite, w <= 32) -> M = D^-1 R^-1 with D = sqrt(diag G), R'R = D^-1 G D^-1 (upper triangular):
-// X M has orthonormal columns when X'X = G.  One thread: ~w^3 / 2 dependent operations, a few microseconds, off the critical path.
-// A G that is not positive definite gives NaNs (the host repeats the factorisation on its copy of G and decides).
-__global__ void k_small_chol(const double *__restrict__ G, int w, double *__restrict__ M)
+// X M has orthonormal columns when X'X = G.  One wave, lane j = column j: a right-looking Cholesky (row i of R, then the rank-one update
+// of the columns behind it: w steps of at most w dependent LDS round trips each) and one back substitution per lane for R^-1 -- about
+// ten microseconds at w = 17, where one thread working through the ~w^3 / 2 dependent operations took 110 (two of these sit on the
+// device's critical path of every trip).  A G that is not positive definite gives NaNs (the host repeats the factorisation on its copy
+// of G and decides).
+__global__ __launch_bounds__(64) void k_small_chol(const double *__restrict__ G, int w, double *__restrict__ M)
 {
     __shared__ double S[32 * 33], Ri[32 * 33], d[32];
     const int t = threadIdx.x;
-    for (int q = t; q < w * w; q += blockDim.x) S[(q / w) * 33 + (q % w)] = G[q]; // S[col][row]
+    const bool mine = t < w;
+    for (int q = t; q < w * w; q += 64) S[(q / w) * 33 + (q % w)] = G[q]; // S[col][row]
     __syncthreads();
-    if (t == 0) {
-        for (int j = 0; j < w; ++j) d[j] = sqrt(S[j * 33 + j]);
-        for (int j = 0; j < w; ++j)
-            for (int i = 0; i < w; ++i) S[j * 33 + i] /= d[i] * d[j];
-        // upper Cholesky, column by column, in place (R[i][j] for i <= j at S[j][i])
-        for (int j = 0; j < w; ++j) {
-            for (int i = 0; i < j; ++i) {
-                double s = S[j * 33 + i];
-                for (int l = 0; l < i; ++l) s -= S[i * 33 + l] * S[j * 33 + l];
-                S[j * 33 + i] = s / S[i * 33 + i];
-            }
-            double s = S[j * 33 + j];
-            for (int l = 0; l < j; ++l) s -= S[j * 33 + l] * S[j * 33 + l];
-            S[j * 33 + j] = sqrt(s);
-        }
-        // inverse of the upper triangular factor
-        for (int j = 0; j < w; ++j) {
-            Ri[j * 33 + j] = 1.0 / S[j * 33 + j];
-            for (int i = j - 1; i >= 0; --i) {
-                double s = 0.0;
-                for (int l = i + 1; l <= j; ++l) s += S[l * 33 + i] * Ri[j * 33 + l];
-                Ri[j * 33 + i] = -s / S[i * 33 + i];
-            }
+    if (mine) d[t] = sqrt(S[t * 33 + t]);
+    __syncthreads();
+    for (int q = t; q < w * w; q += 64) S[(q / w) * 33 + (q % w)] /= d[q % w] * d[q / w];
+    __syncthreads();
+    // R[i][j] (i <= j) ends up at S[j][i]
+    for (int i = 0; i < w; ++i) {
+        const double piv = sqrt(S[i * 33 + i]);
+        double rij = 0.0;
+        if (mine && t >= i) rij = (t == i) ? piv : S[t * 33 + i] / piv;
+        __syncthreads();
+        if (mine && t >= i) S[t * 33 + i] = rij;
+        __syncthreads();
+        if (mine && t > i)
+            for (int l = i + 1; l <= t; ++l) S[t * 33 + l] -= S[l * 33 + i] * rij;
+        __syncthreads();
+    }
+    // column t of R^-1 by back substitution (every lane its own column: no exchange)
+    if (mine) {
+        for (int l = 0; l < w; ++l) Ri[t * 33 + l] = 0.0;
+        for (int i = t; i >= 0; --i) {
+            double s = (i == t) ? 1.0 : 0.0;
+            for (int l = i + 1; l <= t; ++l) s -= S[l * 33 + i] * Ri[t * 33 + l];
+            Ri[t * 33 + i] = s / S[i * 33 + i];
         }
     }
     __syncthreads();
-    for (int q = t; q < w * w; q += blockDim.x) {
+    for (int q = t; q < w * w; q += 64) {
         const int j = q / w, i = q % w;
         M[q] = i <= j ? Ri[j * 33 + i] / d[i] : 0.0;
     }
@@ -517,6 +521,215 @@ extern "C" int rails_panel_gemm_deferred(rails_ctx *c, double alpha, const rails
         C = c->small;
     }
     return rails_panel_gemm_dev(c, alpha, X->d + xc0, X->ld, k, C, r, beta, Y->d + yc0, Y->ld, X->m);
+}
+
+// ---- first update and second projection of a block in ONE pass over the basis ----------------------------------------------------
+// Round 2 of the block orthogonalisation (Stl path: the second sweep of src/StlWrapper.cpp:314-344) needs Y' = Y - X C1 and then
+// C2 = X' Y'.  As two kernels that is two passes over X (2.8 GB each at 350 basis columns x 1M rows: 0.6 + 0.42 ms); here a workgroup
+// takes 16 rows at a time, its four waves split X's columns in interleaved blocks of 16 and keep their part of the tile in registers:
+//   step 1  partial Y' tile = X_part C_part on the MFMA (layout A: lane (row, k mod 4) holds four consecutive columns of its row),
+//           summed over the waves through LDS, Y' written back and kept in LDS;
+//   step 2  C2_part += X_part' Y' : the same registers, turned around through 2 KiB of LDS per wave into the layout in which the
+//           ROWS are the contraction index (lane (column, row mod 4)).
+// Columns beyond 16 of the update (the prefetched random vector that rides at the end of an A*W block: r = 17) are done with plain
+// multiply-adds on the values the lanes hold anyway -- a second MFMA column tile for one column doubles the matrix work and makes the
+// pass MFMA-bound.  The next tile's rows are loaded while this one is worked on.  Per-workgroup partial C2 tiles go to the workspace
+// and are summed in a fixed order by k_reduce_partials, like every Gram matrix here.
+template <int NBW, int NE>
+__global__ __launch_bounds__(256, (NBW <= 6 ? 2 : 1)) void k_update_gram(double alpha, const double *__restrict__ X, int ldx, int k, const double *__restrict__ C, int r,
+                                                     double *Yp, int ldy, int r2, int64_t m, int64_t ntiles, double *__restrict__ partial)
+{
+    constexpr int KMAX = 64 * NBW, RL = 20; // LDS row length of C (doubles): 16 + 4 keeps the four k-groups of a read on disjoint banks
+    __shared__ double Cs[KMAX * RL];
+    __shared__ double red[4][4][64]; // step-1 partial tiles: [wave][result register][lane]
+    __shared__ double rede[4][1][16];
+    __shared__ double awL[16 * 16];  // the updated tile, [row][column], zero beyond r2 columns / m rows
+    __shared__ __attribute__((aligned(16))) double T[4][16 * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    for (int idx = threadIdx.x; idx < KMAX * RL; idx += 256) {
+        const int kl = idx / RL, j = idx % RL;
+        Cs[idx] = (kl < k && j < r) ? C[kl + (int64_t)j * k] : 0.0;
+    }
+    v4f64 acc2[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) acc2[b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    // Loads without branches and without selects (either makes the compiler wait for a block's loads before it issues the next
+    // block's: six memory latencies per tile): addresses are clamped into the panel and what comes back from outside the operands is
+    // multiplied by zeros -- rows past m repeat row m - 1 and meet the zero rows of the Y' tile in step 2 (their step-1 results are
+    // not stored); columns k .. k4 - 1 (k rounded up to 4) are the leading columns of Y itself (the host checks that Y sits right
+    // behind X and is that wide), columns from k4 on repeat column 0, and both meet zero rows of C (rows of C2 that are not written).
+    const int k4 = (k + 3) & ~3;
+    auto fetch = [&](int64_t tile, double (*xs)[4]) {
+        const int64_t myrow = (tile < ntiles ? tile : ntiles - 1) * 16 + li;
+        const double *xrow = X + (myrow < m ? myrow : m - 1) * ldx;
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+            const int kcol = (b * 4 + wave) * 16 + 4 * kk;
+            const double *src = xrow + (kcol < k4 ? kcol : 0);
+            const v2f64 t0 = *reinterpret_cast<const v2f64 *>(src);
+            const v2f64 t1 = *reinterpret_cast<const v2f64 *>(src + 2);
+            xs[b][0] = t0.x;
+            xs[b][1] = t0.y;
+            xs[b][2] = t1.x;
+            xs[b][3] = t1.y;
+        }
+    };
+    // this thread's entry of a tile of Y: result register `wave` of lane `lane` is row kk + 4 wave, column li; the threads that finish
+    // the columns beyond 16: row erow, column 16 + ene
+    const int erow = threadIdx.x & 15, ene = threadIdx.x >> 4;
+    auto fetch_y = [&](int64_t tile, double &yv, double &ye) {
+        const int64_t t16 = (tile < ntiles ? tile : ntiles - 1) * 16;
+        const int64_t yrow = t16 + kk + 4 * wave, er = t16 + erow;
+        yv = Yp[(yrow < m ? yrow : m - 1) * ldy + (li < r ? li : 0)]; // (used only where it is valid)
+        ye = NE > 0 ? Yp[(er < m ? er : m - 1) * ldy + (16 + ene < r ? 16 + ene : 0)] : 0.0;
+    };
+    // one tile: `xs`, `yv`, `ye` were requested while the tile before was worked on; the next tile's go out first (two register sets
+    // that swap roles: no copies, and a wait for this tile's values does not wait for the next one's)
+    auto work = [&](int64_t tile, double (*xs)[4], double yv, double ye, double (*xn)[4], double &yvn, double &yen) {
+        const int64_t row0 = tile * 16;
+        fetch(tile + gridDim.x, xn); // (zeros past the last tile)
+        fetch_y(tile + gridDim.x, yvn, yen);
+        const int64_t yrow = row0 + kk + 4 * wave;
+        const bool yok = yrow < m && li < r;
+        const bool eok = ene < NE && 16 + ene < r && row0 + erow < m;
+        // step 1
+        v4f64 p = (v4f64){0.0, 0.0, 0.0, 0.0};
+        double e[NE > 0 ? NE : 1];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) e[q] = 0.0;
+#pragma unroll
+        for (int b = 0; b < NBW; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double *crow = &Cs[((b * 4 + wave) * 16 + 4 * kk + s) * RL];
+                p = mfma_f64(xs[b][s], crow[li], p);
+#pragma unroll
+                for (int q = 0; q < NE; ++q) e[q] += xs[b][s] * crow[16 + q];
+            }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[wave][v][lane] = p[v];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            double t = e[q];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (kk == 0) rede[wave][q][li] = t;
+        }
+        __syncthreads();
+        {
+            const double sum = ((red[0][wave][lane] + red[1][wave][lane]) + red[2][wave][lane]) + red[3][wave][lane];
+            const double ynew = yv + alpha * sum;
+            if (yok) Yp[yrow * ldy + li] = ynew;
+            awL[(kk + 4 * wave) * 16 + li] = (yok && li < r2) ? ynew : 0.0;
+            if (NE > 0 && eok) {
+                const double se = ((rede[0][ene][erow] + rede[1][ene][erow]) + rede[2][ene][erow]) + rede[3][ene][erow];
+                Yp[(row0 + erow) * ldy + 16 + ene] = ye + alpha * se;
+            }
+        }
+        __syncthreads();
+        // step 2
+        double bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = awL[(4 * q + kk) * 16 + li];
+        double *Tw = T[wave];
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+            *reinterpret_cast<v2f64 *>(&Tw[li * 16 + 4 * kk]) = (v2f64){xs[b][0], xs[b][1]};
+            *reinterpret_cast<v2f64 *>(&Tw[li * 16 + 4 * kk + 2]) = (v2f64){xs[b][2], xs[b][3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double a4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a4[q] = Tw[(4 * q + kk) * 16 + li];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc2[b] = mfma_f64(a4[q], bq[q], acc2[b]);
+        }
+    };
+    double xa[NBW][4], xb[NBW][4], yva, yea, yvb, yeb;
+    fetch(blockIdx.x, xa);
+    fetch_y(blockIdx.x, yva, yea);
+    __syncthreads();
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += 2 * (int64_t)gridDim.x) {
+        work(tile, xa, yva, yea, xb, yvb, yeb);
+        if (tile + gridDim.x < ntiles) work(tile + gridDim.x, xb, yvb, yeb, xa, yva, yea);
+    }
+    double *P = partial + (int64_t)blockIdx.x * k * r2;
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ci = (b * 4 + wave) * 16 + kk + 4 * v; // D row -> X column
+            if (ci < k && li < r2) P[ci + (int64_t)li * k] = acc2[b][v];
+        }
+}
+
+template <int NBW>
+static void launch_update_gram(rails_ctx *c, int ne, unsigned grid, double alpha, const double *X, int ldx, int k, const double *C, int r, double *Y, int ldy, int r2,
+                               int64_t m, int64_t ntiles)
+{
+    if (ne == 0)
+        RAILS_LAUNCH((k_update_gram<NBW, 0>), dim3(grid), dim3(256), 0, c->stream, alpha, X, ldx, k, C, r, Y, ldy, r2, m, ntiles, c->ws);
+    else
+        RAILS_LAUNCH((k_update_gram<NBW, 1>), dim3(grid), dim3(256), 0, c->stream, alpha, X, ldx, k, C, r, Y, ldy, r2, m, ntiles, c->ws);
+}
+
+// Y[:, yc0:yc0+r] += alpha X[:, xc0:xc0+k] C (C on the host, k x r, leading dimension ldc), then slot <- X[:, xc0:xc0+k]' Y[:, yc0:yc0+r2]
+// (k x r2, leading dimension k, summed over the ranks, on its way to the slot's pinned mirror).  One pass over X where the shapes
+// allow (r <= 17, r2 <= 16, 32 <= k <= 512), the two separate kernels otherwise.
+extern "C" int rails_update_gram_deferred(rails_ctx *c, double alpha, const rails_panel *X, int xc0, int k, const double *C_host, int ldc, int r,
+                                          rails_panel *Y, int yc0, int r2, int slot)
+{
+    if (c) hipSetDevice(c->device);
+    rails_slow_guard slow__(c, "rails_update_gram_deferred", k, r);
+    RAILS_REQUIRE(c && X && Y && C_host, "rails_update_gram_deferred: null argument");
+    RAILS_REQUIRE(k >= 1 && r >= 1 && r <= 256 && r2 >= 1 && r2 <= r && ldc >= k && xc0 >= 0 && yc0 >= 0 && xc0 + k <= X->cap && yc0 + r <= Y->cap && X->m == Y->m,
+                  "rails_update_gram_deferred: bad shapes");
+    if (X->d == Y->d) RAILS_REQUIRE(xc0 + k <= yc0 || yc0 + r <= xc0, "rails_update_gram_deferred: overlapping windows of one panel");
+    const size_t n = (size_t)k * r2;
+    RAILS_SLOT_CHECK(slot, n, "rails_update_gram_deferred");
+    double *out = c->defer_dev + (size_t)slot * c->defer_slot;
+    if (X->m == 0) {
+        RAILS_HIP_CHECK(hipMemsetAsync(out, 0, n * sizeof(double), c->stream));
+    } else {
+        const size_t nc = (size_t)k * r;
+        RAILS_TRY(rails_small_reserve(c, nc * sizeof(double)));
+        RAILS_TRY(rails_pinned_begin_write(c, nc * sizeof(double)));
+        for (int j = 0; j < r; ++j) memcpy(c->pinned + (size_t)j * k, C_host + (size_t)j * ldc, sizeof(double) * k);
+        RAILS_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, nc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        RAILS_TRY(rails_pinned_end_write(c));
+        static const int fused_env = getenv("RAILS_FUSED_UPDATE_GRAM") ? atoi(getenv("RAILS_FUSED_UPDATE_GRAM")) : 1;
+        const double *Xp = X->d + xc0;
+        double *Ypp = Y->d + yc0;
+        // (16-byte loads of four columns at a time: aligned rows, and the columns between k and k rounded up to 4 are Y's own)
+        const int k4 = (k + 3) & ~3;
+        const bool rows_ok = ((((uintptr_t)Xp) & 15) == 0 && (X->ld % 2) == 0) && (k4 == k || (X->d == Y->d && yc0 == xc0 + k && r >= k4 - k));
+        if (fused_env && rows_ok && r <= 17 && r2 <= 16 && k >= 32 && k <= 512 && X->m >= 4096) {
+            const int64_t ntiles = (X->m + 15) / 16;
+            const unsigned grid = (unsigned)std::min<int64_t>(ntiles, 2 * (int64_t)std::max(c->num_cu, 1));
+            const int ne = r > 16 ? r - 16 : 0;
+            RAILS_TRY(rails_ws_reserve(c, (size_t)grid * n * sizeof(double)));
+            if (k <= 256)
+                launch_update_gram<4>(c, ne, grid, alpha, Xp, X->ld, k, c->small, r, Ypp, Y->ld, r2, X->m, ntiles);
+            else if (k <= 384)
+                launch_update_gram<6>(c, ne, grid, alpha, Xp, X->ld, k, c->small, r, Ypp, Y->ld, r2, X->m, ntiles);
+            else
+                launch_update_gram<8>(c, ne, grid, alpha, Xp, X->ld, k, c->small, r, Ypp, Y->ld, r2, X->m, ntiles);
+            RAILS_LAUNCH(k_reduce_partials, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, c->stream, c->ws, (int64_t)grid, (int64_t)n, out);
+            RAILS_HIP_CHECK(hipGetLastError());
+            c->n_update_gram_fused++;
+        } else {
+            RAILS_TRY(rails_panel_gemm_dev(c, alpha, Xp, X->ld, k, c->small, r, 1.0, Ypp, Y->ld, X->m));
+            RAILS_TRY(rails_gram_dev(c, Xp, X->ld, Ypp, Y->ld, X->m, k, r2, out));
+        }
+    }
+    RAILS_TRY(rails_allreduce_dev(c, out, n));
+    RAILS_HIP_CHECK(hipMemcpyAsync(c->defer_pin + (size_t)slot * c->defer_slot, out, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return RAILS_OK;
 }
 
 // slot_out <- D^-1 R^-1 for the w x w Gram matrix in slot_in (see k_small_chol)

@@ -88,7 +88,7 @@ struct rails_ctx {
     double gpu_busy_ms = 0.0;
     // counters (rails_ctx_stats)
     void *lz = nullptr; // rails_lanczos_state (lanczos.hip), released by rails_lanczos_release
-    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_sweep = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_dev_alloc = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0;
+    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_sweep = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_dev_alloc = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0, n_update_gram_fused = 0;
 };
 
 // the busy meter (see rails_ctx): RAILS_LAUNCH brackets a launch, rails_stream_sync reads what has been bracketed since the last one

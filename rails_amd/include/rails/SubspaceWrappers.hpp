@@ -234,7 +234,6 @@ public:
             std::vector<double> c2(wr, 0.0); // squared length of what this round finds along P, per column
             for (int j = 0; j < wr; ++j)
                 for (int i = 0; i < dim; ++i) c2[j] += CG[i + (size_t)j * dw] * CG[i + (size_t)j * dw];
-            if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, CG.data(), dw, wr, 1.0, pp, dim), "rails_panel_gemm")) return fail();
             for (int j = 0; j < wr; ++j)
                 for (int i = 0; i < dim; ++i) coef[i + (size_t)j * ld] += CG[i + (size_t)j * dw];
             if (round == 0) {
@@ -254,7 +253,9 @@ public:
                     if (!(surv > reorth_survival)) w2 = j + 1;
                 }
                 if (trace) std::cerr << "absorb: dim " << dim << " w " << w << " first round: smallest survival " << worst << ", second round on " << w2 << " columns" << std::endl;
+                // (the overlapped form queues the update of this round itself: fused with the second projection, one pass over P)
                 if (overlap && w <= 32 && worst >= overlap_min_survival && start_overlapped(w, w2, coef, CG, G0)) return true;
+                if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, CG.data(), dw, wr, 1.0, pp, dim), "rails_panel_gemm")) return fail();
                 if (w2 == 0) break;
                 n_second_round++;
                 if (w2 < w) { // keep what the Gram entries of the untouched columns need
@@ -262,6 +263,7 @@ public:
                     for (int j = w2; j < w; ++j) memcpy(C1t.data() + (size_t)(j - w2) * dim, CG.data() + (size_t)j * dw, sizeof(double) * dim);
                 }
             } else {
+                if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, CG.data(), dw, wr, 1.0, pp, dim), "rails_panel_gemm")) return fail();
                 // The block's Gram matrix after the second round.  Columns i, j < w2: the one just measured minus the (tiny) second
                 // correction.  One of them >= w2: as measured (the correction term is the product of two rounding-level quantities).
                 // Both >= w2 (projected once, more than half survived): the first Gram matrix minus the first correction.
@@ -507,14 +509,16 @@ public:
         for (int a = 0; a < w; ++a)
             if (!(R1[a + (size_t)a * w] > 1e-2)) return false; // an ill-conditioned block takes the careful way (re-projection)
         if (!hip_ok(rails_deferred_reserve(ctx, N_SLOTS, (int64_t)(P.capacity() + 64) * 32), "rails_deferred_reserve")) return false;
-        // the device's part, queued behind the first update: second round on the leading w2 columns, Gram matrix of the block, its
-        // Cholesky factor inverted, Q1 = X M1, the same once more (CholQR2)
+        // the device's part: the first update, the second round on the leading w2 columns, Gram matrix of the block, its Cholesky
+        // factor inverted, Q1 = X M1, the same once more (CholQR2)
         rails_panel *pp = P.panel();
         bool ok = true;
         if (w2 > 0) {
-            ok = ok && hip_ok(rails_gram_deferred(ctx, pp, 0, dim, pp, dim, w2, SLOT_C2), "rails_gram_deferred");
+            // first update and second projection in one pass over P (rails_update_gram_deferred), then the second update from the slot
+            ok = ok && hip_ok(rails_update_gram_deferred(ctx, -1.0, pp, 0, dim, CG.data(), dw, w, pp, dim, w2, SLOT_C2), "rails_update_gram_deferred");
             ok = ok && hip_ok(rails_panel_gemm_deferred(ctx, -1.0, pp, 0, dim, SLOT_C2, dim, w2, 1.0, pp, dim), "rails_panel_gemm_deferred");
-        }
+        } else
+            ok = ok && hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, CG.data(), dw, w, 1.0, pp, dim), "rails_panel_gemm");
         ok = ok && hip_ok(rails_gram_deferred(ctx, pp, dim, w, pp, dim, w, SLOT_G), "rails_gram_deferred");
         ok = ok && hip_ok(rails_chol_inverse_deferred(ctx, SLOT_G, w, SLOT_M1), "rails_chol_inverse_deferred");
         ok = ok && hip_ok(rails_panel_gemm_deferred(ctx, 1.0, pp, dim, w, SLOT_M1, w, w, 0.0, pp, dim), "rails_panel_gemm_deferred");

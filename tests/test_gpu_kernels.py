@@ -501,3 +501,70 @@ def test_deferred_small_results(ctx):
     np.testing.assert_allclose(M, np.triu(np.linalg.inv(R) / d[:, None]), rtol=1e-9, atol=1e-12 * np.abs(M).max())
     np.testing.assert_allclose(fetch(3, w, w), np.eye(w), rtol=0, atol=1e-10)
     np.testing.assert_allclose(X.to_host()[:, a:], Xw1 @ M, rtol=0, atol=1e-10 * np.abs(Xw1 @ M).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,r,r2,xoff", [(50000, 100, 17, 16, 0), (60007, 352, 17, 16, 0), (40000, 300, 16, 16, 2), (30000, 420, 17, 12, 0),
+                                           (20000, 64, 5, 3, 0), (50000, 200, 17, 16, 1), (50000, 120, 20, 18, 0), (3000, 90, 17, 16, 0)])
+def test_update_and_second_projection_in_one_pass(ctx, m, k, r, r2, xoff):
+    """rails_update_gram_deferred (include/rails_hip.h): Y += alpha X C, then slot <- X' Y[:, :r2], as one pass over X (k_update_gram:
+    16 MFMA columns + the 17th on the vector unit; odd window offsets, 20 columns or few rows take the two separate kernels) against numpy.  The second sweep of the reference's block Gram-Schmidt (src/StlWrapper.cpp:314-344)."""
+    import ctypes as C
+
+    import rails_amd
+
+    lib = ctx.lib
+    chk = rails_amd._lib.check
+    g = np.random.default_rng(m + k)
+    Xh = g.uniform(-1, 1, (m, xoff + k + r + 3))
+    X = rails_amd.HipMultiVectorWrapper(ctx, data=Xh)
+    P = X.panel.h
+    Ch = np.asfortranarray(g.uniform(-1, 1, (k + 5, r)))  # leading dimension k + 5
+    dp = C.POINTER(C.c_double)
+    chk(lib.rails_deferred_reserve(ctx.h, 3, (k + 64) * 32), "rails_deferred_reserve")
+    before = ctx.stats().get("update_gram_fused", 0)
+    chk(lib.rails_update_gram_deferred(ctx.h, -0.5, P, xoff, k, Ch.ctypes.data_as(dp), k + 5, r, P, xoff + k, r2, 1), "rails_update_gram_deferred")
+    ctx.sync()
+    fused = ctx.stats().get("update_gram_fused", 0) - before
+    assert fused == (1 if (r <= 17 and m >= 4096 and xoff % 2 == 0) else 0)
+    Xa = Xh[:, xoff:xoff + k]
+    Ynew = Xh[:, xoff + k:xoff + k + r] - 0.5 * (Xa @ Ch[:k])
+    out = X.to_host()
+    scale = np.abs(Ynew).max()
+    np.testing.assert_allclose(out[:, xoff + k:xoff + k + r], Ynew, rtol=0, atol=1e-13 * k * scale)
+    assert np.array_equal(out[:, :xoff + k], Xh[:, :xoff + k]) and np.array_equal(out[:, xoff + k + r:], Xh[:, xoff + k + r:])
+    C2 = np.zeros((k, r2), order="F")
+    chk(lib.rails_deferred_fetch(ctx.h, 1, k * r2, C2.ctypes.data_as(dp)), "fetch")
+    ref = Xa.T @ Ynew[:, :r2]
+    np.testing.assert_allclose(C2, ref, rtol=0, atol=1e-13 * m * scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w", [1, 2, 16, 17, 31, 32])
+def test_small_cholesky_inverse_on_the_device(ctx, w):
+    """rails_chol_inverse_deferred (k_small_chol: one wave, a column per lane): M = D^-1 R^-1 with R'R = D^-1 G D^-1, so that M' G M = I,
+    for every block width the back end uses, on a Gram matrix with a wide range of column norms."""
+    import ctypes as C
+
+    import rails_amd
+
+    lib = ctx.lib
+    chk = rails_amd._lib.check
+    g = np.random.default_rng(w)
+    m = 20000
+    Xh = g.uniform(-1, 1, (m, w)) * np.logspace(0, 5, w)[None, :]
+    X = rails_amd.HipMultiVectorWrapper(ctx, data=Xh)
+    chk(lib.rails_deferred_reserve(ctx.h, 3, 64 * 32), "rails_deferred_reserve")
+    chk(lib.rails_gram_deferred(ctx.h, X.panel.h, 0, w, X.panel.h, 0, w, 0), "gram")
+    chk(lib.rails_chol_inverse_deferred(ctx.h, 0, w, 1), "chol")
+    ctx.sync()
+    dp = C.POINTER(C.c_double)
+    G = np.zeros((w, w), order="F")
+    M = np.zeros((w, w), order="F")
+    chk(lib.rails_deferred_fetch(ctx.h, 0, w * w, G.ctypes.data_as(dp)), "fetch")
+    chk(lib.rails_deferred_fetch(ctx.h, 1, w * w, M.ctypes.data_as(dp)), "fetch")
+    assert np.array_equal(M, np.triu(M))
+    np.testing.assert_allclose(M.T @ G @ M, np.eye(w), rtol=0, atol=1e-11)
+    d = np.sqrt(np.diag(G))
+    R = np.linalg.cholesky(G / np.outer(d, d)).T
+    np.testing.assert_allclose(M, np.triu(np.linalg.inv(R) / d[:, None]), rtol=1e-8, atol=1e-12 * np.abs(M).max())
