@@ -226,9 +226,101 @@ __global__ __launch_bounds__(256) void k_spmm_rowgather_cc(int64_t m, const int6
     }
 }
 
-template <int LPR>
-int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool y_vec = true)
+// Kernel 1c: the in-loop product A * W at Expand size <= 16 on operators whose X rows are all addressable as X + c * ldx with 32-bit
+// byte offsets (no ghost rows, panel below 4 GiB, fewer than 2^24 rows).  Same scheme as kernel 1b with one chunk -- 8 lanes own a row,
+// the block's (col, val) run staged in LDS -- but the per-nonzero work is cut to what the product needs: two LDS broadcasts, one
+// 24-bit multiply-add for the byte offset, one 16-byte load with a scalar base, two multiply-adds.  Kernel 1b spends ~37 vector
+// instructions per nonzero on 64-bit addresses, the ghost-row select and the masks of its tail and ran at the instruction rate
+// (rocprofv3 --pmc: 2000 VALU instructions per wave of 16 rows, TA and L2 far from busy): 0.40 ms at 16 columns, 18 % of the HBM rate.
+template <int RPG>
+__global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                     const double *__restrict__ val, const double *__restrict__ X, uint32_t ldx8,
+                                                     double *__restrict__ Y, int ldy, int nc, int64_t blocks_per_xcd, int y_vec)
 {
+    constexpr int LPR = 8, GROUPS = 256 / LPR, ROWS = GROUPS * RPG, CAP = 2048;
+    __shared__ double s_val[CAP];
+    __shared__ int32_t s_col[CAP];
+    const int g = threadIdx.x / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t lb = (int64_t)(blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
+    const int64_t r0 = lb * ROWS;
+    if (r0 >= m) return;
+    const int64_t r1 = (r0 + ROWS < m) ? r0 + ROWS : m;
+    const int64_t nz0 = rowptr[r0], nz1 = rowptr[r1];
+    const bool staged = (nz1 - nz0) <= CAP; // block-uniform
+    if (staged) {
+        for (int q = threadIdx.x; q < (int)(nz1 - nz0); q += 256) {
+            s_col[q] = col[nz0 + q];
+            s_val[q] = val[nz0 + q];
+        }
+        __syncthreads();
+    }
+    const int cb = l * 2;
+    if (cb >= nc) return;
+    const bool full = (cb + 2 <= nc);
+    const uint32_t cb8 = (uint32_t)cb * 8u;
+    const char *Xb = reinterpret_cast<const char *>(X);
+    for (int rr = 0; rr < RPG; ++rr) {
+        const int64_t row = r0 + (int64_t)rr * GROUPS + g; // the 32 rows in flight are consecutive
+        if (row >= m) break;
+        double2_t acc = (double2_t){0.0, 0.0};
+        if (staged && full) {
+            int i = (int)(rowptr[row] - nz0);
+            const int i1 = (int)(rowptr[row + 1] - nz0);
+            for (; i + 8 <= i1; i += 8) {
+                double2_t x[8];
+                double a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    x[u] = *reinterpret_cast<const double2_t *>(Xb + (__umul24((uint32_t)s_col[i + u], ldx8) + cb8));
+                    a[u] = s_val[i + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc.x = __builtin_fma(a[u], x[u].x, acc.x);
+                    acc.y = __builtin_fma(a[u], x[u].y, acc.y);
+                }
+            }
+            for (; i < i1; i += 4) { // the last one to seven: groups of four, the slots past the end repeat the last entry with a zero
+                double2_t x[4];
+                double a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = i + u < i1 ? i + u : i1 - 1;
+                    x[u] = *reinterpret_cast<const double2_t *>(Xb + (__umul24((uint32_t)s_col[q], ldx8) + cb8));
+                    a[u] = i + u < i1 ? s_val[q] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x = __builtin_fma(a[u], x[u].x, acc.x);
+                    acc.y = __builtin_fma(a[u], x[u].y, acc.y);
+                }
+            }
+        } else {
+            // (a block with more nonzeros than the LDS buffer holds, or the lane of an odd last column: one entry at a time)
+            for (int64_t p = rowptr[row]; p < rowptr[row + 1]; ++p) {
+                const double a = val[p];
+                const double *src = reinterpret_cast<const double *>(Xb + (__umul24((uint32_t)col[p], ldx8) + cb8));
+                acc.x = __builtin_fma(a, src[0], acc.x);
+                if (full) acc.y = __builtin_fma(a, src[1], acc.y);
+            }
+        }
+        double *dst = Y + row * ldy + cb;
+        if (full && y_vec)
+            *reinterpret_cast<double2_t *>(dst) = acc;
+        else if (full) { // Y window starts on an odd column: two 8-byte stores
+            dst[0] = acc.x;
+            dst[1] = acc.y;
+        } else
+            *dst = acc.x;
+    }
+}
+
+template <int LPR>
+int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool y_vec = true,
+                 const char **kernel = nullptr)
+{
+    if (kernel) *kernel = "k_spmm_rowgather_cc";
     constexpr int GROUPS = 256 / LPR;
     constexpr int RPG = (LPR >= 32) ? 8 : (LPR >= 16 ? 4 : 2);
     constexpr int ROWS = GROUPS * RPG; // 64 rows per block
@@ -239,6 +331,17 @@ int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, con
     const int64_t grid = bpx * 8 * nchunks;
     RAILS_REQUIRE(grid <= 0x7fffffffLL, "rails_spmm: grid too large");
     const int lds_cap = 2048; // nonzeros of one block staged in LDS (24 KiB); longer runs read (col, val) from global memory
+    if (LPR == 8 && nchunks == 1) {
+        // every X row at X + c * ldx (no ghost rows; a rectangular operator's extra rows follow X in the same panel) within 32-bit byte offsets
+        static const int narrow_fast = spmm_env("RAILS_SPMM_NARROW_FAST", 1);
+        const bool flat = (A->n_ghost == 0 && !A->rect) || (Xg == X + (int64_t)A->m * ldx && ldg == ldx);
+        if (narrow_fast && flat && A->ncols_ext < (1 << 24) && (int64_t)ldx * 8 < (1 << 24) && (uint64_t)A->ncols_ext * (uint64_t)ldx * 8u < 0xffffff00ull) {
+            RAILS_LAUNCH((k_spmm_narrow<RPG>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, Y, ldy, nc, bpx,
+                         y_vec ? 1 : 0);
+            if (kernel) *kernel = "k_spmm_narrow";
+            return RAILS_OK;
+        }
+    }
     RAILS_LAUNCH((k_spmm_rowgather_cc<LPR, RPG>), dim3((unsigned)grid), dim3(256), (size_t)lds_cap * 12, c->stream, A->m, A->rowptr,
                        A->col, A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx, lds_cap, y_vec ? 1 : 0);
     return RAILS_OK;
@@ -600,8 +703,9 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         const bool x_vec2 = (xc0 & 1) == 0 && (X->ld % 2 == 0) && (ldg % 2 == 0);
         const bool y_vec2 = (yc0 & 1) == 0 && (Y->ld % 2 == 0);
         if (cc == 0 && x_vec2 && narrow_env && A->variant != 3 && nc > 8 && nc <= (narrow_env == 2 ? 32 : 16) && A->max_row_nnz <= 64) cc = nc <= 16 ? 16 : -32;
+        const char *cc_kernel = "k_spmm_rowgather_cc";
         if (cc == 16)
-            RAILS_TRY((launch_rg_cc<8>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, y_vec2)));
+            RAILS_TRY((launch_rg_cc<8>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, y_vec2, &cc_kernel)));
         else if (cc == -32)
             RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, y_vec2)));
         else if (cc == 32)
@@ -613,7 +717,7 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         else
             RAILS_TRY((dispatch_rg<1>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
         if (cc) {
-            A->last_kernel = "k_spmm_rowgather_cc";
+            A->last_kernel = cc_kernel;
             c->n_spmm_rowgather++;
             RAILS_HIP_CHECK(hipGetLastError());
             return RAILS_OK;

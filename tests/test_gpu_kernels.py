@@ -568,3 +568,38 @@ def test_small_cholesky_inverse_on_the_device(ctx, w):
     d = np.sqrt(np.diag(G))
     R = np.linalg.cholesky(G / np.outer(d, d)).T
     np.testing.assert_allclose(M, np.triu(np.linalg.inv(R) / d[:, None]), rtol=1e-8, atol=1e-12 * np.abs(M).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nc,xoff,yoff", [(16, 0, 0), (16, 2, 3), (12, 0, 0), (11, 0, 2), (9, 4, 1)])
+def test_narrow_product_is_bitwise_the_rowgather_result(ctx, oracle, nc, xoff, yoff):
+    """The in-loop product A * W at Expand size <= 16 (`A_ * W`, src/LyapunovSolver.hpp:146; k_spmm_narrow, spmm.hip kernel 1c): rows of
+    0 to 60 entries (full groups of eight, tails of one to seven, blocks whose entries do not fit the LDS buffer), odd last columns and
+    odd output offsets, against the whole-width row-gather kernel bit for bit and against the oracle's CSR product."""
+    import rails_amd
+
+    g = np.random.default_rng(nc + xoff)
+    m = 20000
+    lens = g.integers(0, 28, m)
+    lens[5000:5200] = 60  # 64 consecutive rows x 60 entries: more than the 2048 the kernel stages
+    lens[::97] = 0
+    rowptr = np.zeros(m + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    col = np.concatenate([np.sort(g.choice(m, n, replace=False)) for n in lens]).astype(np.int32)
+    val = g.uniform(-1, 1, col.size)
+    op = rails_amd.HipOperatorWrapper(ctx, rowptr, col, val)
+    Xh = g.uniform(-1, 1, (m, nc))
+    big = MV(ctx, m=m, n=nc + xoff, capacity=nc + xoff + 1)
+    X = big.view(xoff, xoff + nc - 1)
+    X.from_host(Xh)
+    outp = MV(ctx, m=m, n=nc + yoff, capacity=nc + yoff + 3)
+    Y = outp.view(yoff, yoff + nc - 1)
+    op.apply(X, Y)
+    assert op.last_kernel() == "k_spmm_narrow"
+    Yn = Y.to_host()
+    op.set_variant(3)
+    Y3 = op.apply(X)
+    assert op.last_kernel() == "k_spmm_rowgather"
+    assert np.array_equal(Y3.to_host(), Yn)
+    ref = oracle.csr_spmm(rowptr, col, val, Xh)
+    assert np.abs(Yn - ref).max() <= 1e-14 * np.sqrt(60) * 4 * np.abs(ref).max()
