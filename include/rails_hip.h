@@ -165,10 +165,10 @@ int rails_csr_create_rect(rails_ctx *ctx, int64_t n_rows, int64_t n_cols, const 
 const char *rails_csr_last_kernel(const rails_csr *A);
 
 /* Host-side schedule of the sweep kernel (rails_amd/csrc/sweep_plan.h), exposed for tests and diagnostics: no device is
- * touched.  params = {waves, groups, rows per step, ring segments, parts, phases, segments being filled at any time} (7
- * entries) or NULL for the kernel's own geometry.
+ * touched.  params = {waves, groups, rows per step, ring segments, parts, phases, segments being filled at any time, trips per
+ * schedule entry (4 or 2; 0 = the library's choice)} (8 entries) or NULL for the kernel's own geometry.
  * info (iinfo has room for 16): iinfo[0..5] = params, [6] entries per step record, [7] lock-step trips, [8] nnz, [9] batches,
- * [10] units in the busiest (wave, step), [11] slots per wave, [12] segments being filled; dinfo[0] = slot efficiency
+ * [10] entries in the busiest (wave, step), [11] slots per wave, [12] segments being filled, [13] trips per entry; dinfo[0] = slot efficiency
  * nnz / (slots x trips), dinfo[1] = X rows staged per matrix row and column chunk.  rails_sweep_plan_array lends the
  * arrays of the plan (which = 0 part_row0 i64, 1 sweep0 i64, 2 nsteps i32, 3 hdr_off i64, 4 batch_off i64, 5 flush_off i64,
  * 6 codes u32, 7 vals f64, 8 offs u16, 9 flush_rows i32); they live until rails_sweep_plan_destroy. */

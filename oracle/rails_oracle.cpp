@@ -979,6 +979,7 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
     const int CPS = (int)iinfo[6]; // entries per (program, step) record
     const int AHEAD = (int)iinfo[12]; // segments being refilled at any time
     const int SLOTS = (int)iinfo[11]; // rows of a group in one wave (16: a slot is a quad of lanes)
+    const int ENTRY_TRIPS = iinfo[13] == 2 ? 2 : 4; // trips per schedule entry (a whole unit of the kernel's code, or half of one)
     std::vector<int> written((size_t)m * n_chunks, 0);
     int rc = 0;
 #pragma omp parallel for collapse(2) schedule(dynamic)
@@ -996,7 +997,7 @@ int orc_sweep_interpret(const int64_t *iinfo, const int64_t *part_row0, const in
                             const int n = (int)(rec[0] & 0xff);
                             const uint32_t code = rec[ci];
                             const int g = (int)(code & 0xff) / 8;
-                            const int T = (code & 0x200) ? 0 : 4;
+                            const int T = (code & 0x200) ? 0 : ENTRY_TRIPS;
                             if (g >= G || ci >= CPS || (code & 7)) {
 #pragma omp atomic write
                                 rc = -1;

@@ -63,6 +63,22 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_NAME k_spmm_sweep
 #define RAILS_SW_ABLATE 0 /* the product kernel: no experiment switches */
 #define RAILS_SW_PIPELINED 1
+#define RAILS_SW_ENTRY_TRIPS 4
+#define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
+#define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
+#define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
+#define RAILS_SW_FMA(TEXT) TEXT
+#define RAILS_SW_VMWAIT(TEXT) TEXT
+#define RAILS_SW_IDX(TEXT) TEXT
+#define RAILS_SW_DPPSFX "_dpp"
+#define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#include "spmm_sweep_kernel.inc"
+// the same kernel for schedules whose entries are half units (rails_sweep_params::entry_trips == 2): every half of a unit of the code
+// fetches its own entry, so that the two halves may serve different groups
+#define RAILS_SW_NAME k_spmm_sweep_h2
+#define RAILS_SW_ABLATE 0
+#define RAILS_SW_PIPELINED 0
+#define RAILS_SW_ENTRY_TRIPS 2
 #define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
 #define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -76,6 +92,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_NAME k_spmm_sweep_switches
 #define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_PIPELINED 1
+#define RAILS_SW_ENTRY_TRIPS 4
 #define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
 #define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -89,6 +106,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_NAME k_spmm_sweep_halves
 #define RAILS_SW_ABLATE 0
 #define RAILS_SW_PIPELINED 0
+#define RAILS_SW_ENTRY_TRIPS 4
 #define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
 #define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -102,6 +120,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_NAME k_spmm_sweep_noread
 #define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_PIPELINED 0
+#define RAILS_SW_ENTRY_TRIPS 4
 #define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
 #define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) ""
@@ -114,6 +133,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_NAME k_spmm_sweep_nofma
 #define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_PIPELINED 0
+#define RAILS_SW_ENTRY_TRIPS 4
 #define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
 #define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -126,6 +146,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_NAME k_spmm_sweep_nowait
 #define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_PIPELINED 0
+#define RAILS_SW_ENTRY_TRIPS 4
 #define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
 #define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -138,6 +159,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_NAME k_spmm_sweep_noidx
 #define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_PIPELINED 0
+#define RAILS_SW_ENTRY_TRIPS 4
 #define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
 #define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -150,6 +172,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_NAME k_spmm_sweep_bare
 #define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_PIPELINED 0
+#define RAILS_SW_ENTRY_TRIPS 4
 #define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
 #define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) ""
@@ -162,6 +185,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_NAME k_spmm_sweep_nodpp
 #define RAILS_SW_ABLATE a.ablate
 #define RAILS_SW_PIPELINED 0
+#define RAILS_SW_ENTRY_TRIPS 4
 #define RAILS_SW_WAITA "s_waitcnt lgkmcnt(2)\n\t"
 #define RAILS_SW_WAITB "s_waitcnt lgkmcnt(0)\n\t"
 #define RAILS_SW_READ(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n\t"
@@ -243,7 +267,14 @@ static int ensure_plan(rails_ctx *c, rails_csr *A, int n_chunks, DevPlan **out)
         if (getenv("RAILS_SWEEP_LEVEL")) prm.level = atoi(getenv("RAILS_SWEEP_LEVEL")); // experiments: 0 = no levelling of the waves
         if (getenv("RAILS_SWEEP_MIN_FILL")) prm.level_min_fill = atoi(getenv("RAILS_SWEEP_MIN_FILL"));
         if (getenv("RAILS_SWEEP_SLACK")) prm.level_slack = atoi(getenv("RAILS_SWEEP_SLACK"));
-        if (rails_sweep_plan_build(prm, A->m, A->ncols_ext, A->h_rowptr.data(), A->h_col.data(), A->h_val.data(), d->host)) {
+        if (getenv("RAILS_SWEEP_ENTRY_TRIPS")) prm.entry_trips = atoi(getenv("RAILS_SWEEP_ENTRY_TRIPS")) == 4 ? 4 : 2; // 4: entries of whole units (k_spmm_sweep)
+        if (getenv("RAILS_SWEEP_ABLATE") && atoi(getenv("RAILS_SWEEP_ABLATE"))) prm.entry_trips = 4;                  // (the experiment builds take those)
+        bool built = rails_sweep_plan_build(prm, A->m, A->ncols_ext, A->h_rowptr.data(), A->h_col.data(), A->h_val.data(), d->host);
+        if (!built && prm.entry_trips == 2) { // heavy rows: twice the entries do not fit a step's record; whole units may
+            prm.entry_trips = 4;
+            built = rails_sweep_plan_build(prm, A->m, A->ncols_ext, A->h_rowptr.data(), A->h_col.data(), A->h_val.data(), d->host);
+        }
+        if (built) {
             RAILS_TRY(up(c, &d->part_row0, d->host.part_row0));
             RAILS_TRY(up(c, &d->sweep0, d->host.sweep0));
             RAILS_TRY(up(c, &d->nsteps, d->host.nsteps));
@@ -326,6 +357,10 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
 #define RAILS_SWEEP_LAUNCH(K)                                                                                                                     \
     RAILS_LAUNCH((K<SWEEP_W, SWEEP_G>), dim3(256), dim3(SWEEP_W * 64), 0, c->stream, a, d->part_row0, d->sweep0, d->nsteps, d->hdr_off, \
                        d->batch_off, d->codes, d->vals, d->offs, X, Xg, Y)
+    if (d->host.p.entry_trips == 2) {
+        RAILS_REQUIRE(!ablate, "rails_spmm: the experiment builds of the sweep kernel take schedules with entries of four trips (RAILS_SWEEP_ENTRY_TRIPS)");
+        RAILS_SWEEP_LAUNCH(k_spmm_sweep_h2);
+    } else
     switch ((ablate >> 4) & 15) {
     case 1: RAILS_SWEEP_LAUNCH(k_spmm_sweep_noread); break;
     case 2: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nofma); break;

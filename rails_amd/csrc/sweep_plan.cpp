@@ -13,11 +13,11 @@ namespace {
 
 constexpr int SLOTS = 16; // rows of a group in one wave: a slot is a quad of lanes, each lane four of the row's 16 columns
 
-// the schedule of one group: its units (four trips each, or a flush without trips) in execution order
+// the schedule of one group: its entries (entry_trips trips each, or a flush without trips) in execution order ("unit" below = entry)
 struct GroupSchedule {
     std::vector<int> step;        // per unit: the step it runs in
     std::vector<uint8_t> flags;   // per unit: 1 = the group's partial sums go to Y afterwards, 2 = no trips
-    std::vector<double> val;      // [units with trips][4][SLOTS]
+    std::vector<double> val;      // [units with trips][entry_trips][SLOTS]
     std::vector<uint16_t> off;
     std::vector<int32_t> flush;   // first row of the wave's slot octet, per flush, in order
 };
@@ -136,7 +136,8 @@ struct GroupRun {
         // the block has to be done before the first X row of the workgroup's next block leaves the ring
         const bool must_finish = next_first != INT64_MAX && (int64_t)k >= next_first + NSEG - 2 - P.ahead;
         need = forced;
-        full = ready == INT_MAX ? 0 : ready / 4 * 4;
+        const int UT = c->prm->entry_trips;
+        full = ready == INT_MAX ? 0 : ready / UT * UT;
         if (must_finish || remaining == 0) {
             if (!all_available) {
                 why = "the column window of a row block is wider than (phases - 1) blocks";
@@ -150,8 +151,9 @@ struct GroupRun {
     // nonzeros unit number n of this step would consume (n = 0: the first)
     int fill_of_unit(int n) const
     {
+        const int UT = c->prm->entry_trips;
         int f = 0;
-        for (int s = 0; s < SLOTS; ++s) f += std::min(std::max(avail[s] - 4 * n, 0), 4);
+        for (int s = 0; s < SLOTS; ++s) f += std::min(std::max(avail[s] - UT * n, 0), UT);
         return f;
     }
 
@@ -160,16 +162,16 @@ struct GroupRun {
         if (!loaded) return true;
         const rails_sweep_params &P = *c->prm;
         const int SEG = P.seg_rows, NSEG = P.nseg;
-        const int ring = SEG * NSEG;
+        const int ring = SEG * NSEG, UT = P.entry_trips;
         if (units > 127) {
-            why = "more than 508 nonzeros of one row inside one ring of X rows";
+            why = "more than 127 entries of one group in one step (hundreds of nonzeros of one row inside one ring of X rows)";
             return false;
         }
         for (int u = 0; u < units; ++u) {
             double v[4][SLOTS];
             int64_t o[4][SLOTS];
             int64_t first_real = -1;
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < UT; ++t)
                 for (int s = 0; s < SLOTS; ++s) {
                     v[t][s] = 0.0;
                     o[t][s] = -1;
@@ -186,7 +188,7 @@ struct GroupRun {
             if (first_real < 0) break; // nothing left that has arrived
             // an idle slot multiplies an X row by zero: the row of its own previous nonzero while that is still in the ring, else
             // the first row this unit reads anyway
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < UT; ++t)
                 for (int s = 0; s < SLOTS; ++s) {
                     if (o[t][s] >= 0)
                         last_pos[s] = o[t][s];
@@ -232,7 +234,7 @@ struct GroupRun {
 bool schedule_part(const Ctx &c, std::vector<std::vector<GroupRun>> &runs, std::vector<int> &pause, std::string &why)
 {
     const rails_sweep_params &P = *c.prm;
-    const int W = P.waves, G = P.groups, NW = P.phases * W;
+    const int W = P.waves, G = P.groups, NW = P.phases * W, UT = P.entry_trips;
     const int cap = RAILS_SWEEP_CODES - 2;
     for (int x = 0; x < NW; ++x)
         for (int g = 0; g < G; ++g) runs[x][g].start(c, x / W, x % W, g);
@@ -245,7 +247,7 @@ bool schedule_part(const Ctx &c, std::vector<std::vector<GroupRun>> &runs, std::
             for (int g = 0; g < G; ++g) {
                 GroupRun &r = runs[x][g];
                 if (!r.look(k, why)) return false;
-                units[(size_t)x * G + g] = (std::max(r.need, r.full) + 3) / 4;
+                units[(size_t)x * G + g] = (std::max(r.need, r.full) + UT - 1) / UT;
                 load[x] += units[(size_t)x * G + g];
             }
         }
@@ -256,7 +258,7 @@ bool schedule_part(const Ctx &c, std::vector<std::vector<GroupRun>> &runs, std::
             for (int w = 0; w < W; ++w) level = std::max(level, load[ph * W + w]);
             for (int x = ph * W; x < (ph + 1) * W; ++x)
                 while (P.level && load[x] < level) {
-                    int best = -1, best_fill = P.level_min_fill - 1;
+                    int best = -1, best_fill = P.level_min_fill * UT / 4 - 1;
                     for (int g = 0; g < G; ++g) {
                         const int f = runs[x][g].fill_of_unit(units[(size_t)x * G + g]);
                         if (f > best_fill) {
@@ -270,7 +272,7 @@ bool schedule_part(const Ctx &c, std::vector<std::vector<GroupRun>> &runs, std::
                 }
             // what the step costs the workgroup, in quarters of a unit's time: measured, 1.24 us for a step without units (the time its X rows
             // take to arrive), 2.2 us for 5.8 units at 0.26 us each
-            spent[ph] += std::max(19, 4 * level + 11);
+            spent[ph] += std::max(19, UT * level + 11);
             furthest = std::max(furthest, spent[ph]);
         }
         // a workgroup whose steps have cost less than another's so far is ahead of it in time: it sits out the difference (beyond the slack)
@@ -309,7 +311,7 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
     plan.ncols = ncols;
     plan.nnz = rowptr[m];
     const int W = prm.waves, G = prm.groups, P = prm.phases, SEG = prm.seg_rows;
-    if (W < 1 || G < 1 || G > 31 || P < 1 || prm.parts < 1 || prm.ahead < 1 || prm.nseg < prm.ahead + 2 || SEG < 8 || SEG % 8 || (int64_t)SEG * prm.nseg > 65536) {
+    if ((prm.entry_trips != 4 && prm.entry_trips != 2) || W < 1 || G < 1 || G > 31 || P < 1 || prm.parts < 1 || prm.ahead < 1 || prm.nseg < prm.ahead + 2 || SEG < 8 || SEG % 8 || (int64_t)SEG * prm.nseg > 65536) {
         plan.why = "bad parameters";
         return false;
     }
@@ -379,12 +381,12 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                         while (up[g] < gr[g].out.step.size() && gr[g].out.step[up[g]] == k) {
                             const uint8_t fl = gr[g].out.flags[up[g]++];
                             if (n + 1 > RAILS_SWEEP_CODES - 1) {
-                                plan.why = "more than 63 units of one wave in one step (step " + std::to_string(k) + " of " + std::to_string(c.nsteps) + ", part " + std::to_string(x) + ")";
+                                plan.why = "more than 63 entries of one wave in one step (step " + std::to_string(k) + " of " + std::to_string(c.nsteps) + ", part " + std::to_string(x) + ")";
                                 return false; // (this part)
                             }
                             rec[1 + n++] = (uint32_t)(g * 8) | ((fl & 1) ? RAILS_SWEEP_FLUSH : 0u) | ((fl & 2) ? RAILS_SWEEP_NO_TRIPS : 0u);
                             if (!(fl & 2)) {
-                                for (int t = 0; t < 4; ++t, ++trip) {
+                                for (int t = 0; t < prm.entry_trips; ++t, ++trip) {
                                     const int64_t b = plan.batch_off[prog] + trip / 16;
                                     if ((size_t)(b + 1) * 256 > plan.vals.size()) {
                                         plan.vals.resize((size_t)(b + 1) * 256, 0.0);
@@ -396,8 +398,8 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                                     const int tt = (int)(trip % 16), unit = tt / 4, ql = tt % 4;
                                     for (int s = 0; s < SLOTS; ++s) {
                                         const size_t lane = (size_t)s * 4 + ql;
-                                        plan.vals[(size_t)b * 256 + (size_t)(unit / 2) * 128 + lane * 2 + (unit % 2)] = gr[g].out.val[(tp[g] * 4 + t) * SLOTS + s];
-                                        plan.offs[(size_t)b * 256 + lane * 4 + unit] = gr[g].out.off[(tp[g] * 4 + t) * SLOTS + s];
+                                        plan.vals[(size_t)b * 256 + (size_t)(unit / 2) * 128 + lane * 2 + (unit % 2)] = gr[g].out.val[(tp[g] * prm.entry_trips + t) * SLOTS + s];
+                                        plan.offs[(size_t)b * 256 + lane * 4 + unit] = gr[g].out.off[(tp[g] * prm.entry_trips + t) * SLOTS + s];
                                     }
                                 }
                                 ++tp[g];
@@ -502,10 +504,12 @@ extern "C" int rails_sweep_plan_create(int64_t m, int64_t ncols, const int64_t *
         prm.parts = params[4];
         prm.phases = params[5];
         prm.ahead = params[6];
+        if (params[7] == 2 || params[7] == 4) prm.entry_trips = params[7];
         if (getenv("RAILS_SWEEP_LEVEL")) prm.level = atoi(getenv("RAILS_SWEEP_LEVEL")); // experiments: 0 = no levelling of the waves
         if (getenv("RAILS_SWEEP_MIN_FILL")) prm.level_min_fill = atoi(getenv("RAILS_SWEEP_MIN_FILL"));
         if (getenv("RAILS_SWEEP_SLACK")) prm.level_slack = atoi(getenv("RAILS_SWEEP_SLACK"));
     }
+    if ((!params || params[7] == 0) && getenv("RAILS_SWEEP_ENTRY_TRIPS")) prm.entry_trips = atoi(getenv("RAILS_SWEEP_ENTRY_TRIPS")) == 4 ? 4 : 2;
     rails_sweep_plan *pl = new rails_sweep_plan();
     if (!rails_sweep_plan_build(prm, m, ncols, rowptr, col, val, *pl)) {
         rails_set_error("rails_sweep_plan_create: pattern does not fit the sweep scheme: %s", pl->why.c_str());
@@ -537,6 +541,7 @@ extern "C" int rails_sweep_plan_info(const rails_sweep_plan *pl, int64_t *iinfo,
     iinfo[9] = (int64_t)(pl->vals.size() / 256);
     iinfo[11] = SLOTS;
     iinfo[12] = pl->p.ahead;
+    iinfo[13] = pl->p.entry_trips;
     iinfo[10] = pl->max_units_per_step;
     dinfo[0] = pl->efficiency;
     dinfo[1] = pl->staged_rows_per_row;

@@ -18,7 +18,8 @@
 //            asked for at the start of step k - ahead and have arrived at the start of step k, during which the lanes may read
 //            positions [(k-NSEG+1+ahead)*SEG, (k+1)*SEG)
 //   trips    one trip = every slot of a wave consumes at most one nonzero of its row (lock step); trips come in units
-//            of four; per step and group the schedule gives the number of units; a group's partial sums are written
+//            of four (the kernel's code and the layout of the stream) and are scheduled in entries of `entry_trips` = 4 or 2
+//            trips; per step and group the schedule gives the number of entries; a group's partial sums are written
 //            to Y when its block is done
 #ifndef RAILS_SWEEP_PLAN_H
 #define RAILS_SWEEP_PLAN_H
@@ -28,7 +29,7 @@
 #include <vector>
 
 constexpr int RAILS_SWEEP_CODES = 64; // 32-bit entries per (program, step) record, one per lane of a wave: a header, then up to 63 entries
-// An entry = one unit of four trips of a group (or a flush without trips): bits 0-7 = 8 x group (the group's first partial-sum register
+// An entry = entry_trips (four or two) trips of a group (or a flush without trips): bits 0-7 = 8 x group (the group's first partial-sum register
 // relative to the first group's); the header: bits 0-7 = number of entries, bits 16-31 = quarters of a unit's time (128 cycles each) to sit out first (pacing).  Flags (the kernel tests them together after a unit):
 constexpr uint32_t RAILS_SWEEP_FLUSH = 0x100;         // the group's partial sums go to Y after this entry
 constexpr uint32_t RAILS_SWEEP_NO_TRIPS = 0x200;      // the entry has no trips (rows without nonzeros left: only the flush)
@@ -47,7 +48,10 @@ struct rails_sweep_params {
     int level = 2;      // 1: the waves of a workgroup run the same number of units in every step; 2: and the workgroups of a part's column
                         // chunk keep pace (pauses); 0: every unit as late as its X rows allow
     int level_slack = 32; // units of time a workgroup may be ahead of the slowest one of its chunk (level 2)
-    int level_min_fill = 16; // a unit run early to level must consume at least this many nonzeros (of 4 x 16)
+    int level_min_fill = 16; // a unit run early to level must consume at least this many nonzeros (of 4 x 16; scaled with entry_trips)
+    int entry_trips = 2;     // trips per schedule entry: 2 = half a unit (the two halves of a unit of the kernel's code may belong to different
+                             // groups: 17 % fewer trips on the benchmark pattern for 4 % more instructions per trip; twice the entries per
+                             // step, so patterns with heavy rows may only fit with whole units); 4 = a whole unit per entry
 };
 
 struct rails_sweep_plan {

@@ -13,7 +13,8 @@ _ARRAYS = [("part_row0", np.int64), ("sweep0", np.int64), ("nsteps", np.int32), 
 
 
 class SweepPlan:
-    """params = (waves, groups, rows per step, ring segments, parts, phases[, segments being filled]) or None for the kernel's geometry."""
+    """params = (waves, groups, rows per step, ring segments, parts, phases[, segments being filled[, trips per entry (4 or 2)]]) or None for
+    the kernel's geometry."""
 
     def __init__(self, rowptr, col, val, ncols=None, params=None):
         lib = _lib.load()
@@ -25,8 +26,9 @@ class SweepPlan:
         self.ncols = int(m if ncols is None else ncols)
         prm = None
         if params is not None:
-            params = list(params) + [1] * (7 - len(params))
-            prm = (C.c_int * 7)(*[int(v) for v in params])
+            params = list(params)
+            params += [1, 0][len(params) - 6:] if len(params) < 8 else []  # defaults: one segment being filled, the library's trips per entry
+            prm = (C.c_int * 8)(*[int(v) for v in params])
         h = C.c_void_p()
         _lib.check(lib.rails_sweep_plan_create(m, self.ncols, rowptr.ctypes.data_as(_lib._i64p), col.ctypes.data_as(_lib._i32p),
                                                val.ctypes.data_as(_lib._dp), prm, C.byref(h)), "rails_sweep_plan_create")
@@ -38,6 +40,7 @@ class SweepPlan:
         self.waves, self.groups, self.seg_rows, self.nseg, self.parts, self.phases, self.codes_per_step, self.trips, self.nnz, self.batches = [int(v) for v in ii[:10]]
         self.slots = int(ii[11])
         self.ahead = int(ii[12])
+        self.entry_trips = int(ii[13])
         self.efficiency, self.staged_rows_per_row = dd[0], dd[1]
         for which, (name, dt) in enumerate(_ARRAYS):
             p = C.c_void_p()

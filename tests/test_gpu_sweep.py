@@ -210,3 +210,42 @@ def test_auto_leaves_structured_stencils_to_the_box_kernel(ctx):
     d = Y.copy()
     d -= Ys
     assert d.norm() <= 1e-13 * Y.norm()  # (the box kernel adds a row's terms in its own order)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry_trips", [2, 4])
+@pytest.mark.parametrize("kind,nc", [("banded", 128), ("banded", 64), ("ragged", 128), ("laplace7", 128), ("banded_narrow", 256)])
+def test_both_entry_sizes_are_bitwise_the_rowgather_result(ctx, monkeypatch, kind, nc, entry_trips):
+    """Both entry sizes of the schedule -- half units (the default: k_spmm_sweep_h2, every half of a unit of the code fetches its own
+    entry) and whole units (RAILS_SWEEP_ENTRY_TRIPS=4: k_spmm_sweep) -- against the row-gather kernel, bit for bit (`A_ * W`,
+    src/LyapunovSolver.hpp:146)."""
+    import rails_amd
+    from rails_amd import problems as P
+
+    monkeypatch.setenv("RAILS_SWEEP_ENTRY_TRIPS", str(entry_trips))
+    g = np.random.default_rng(nc)
+    if kind == "banded":
+        A = P.banded_random(131072 + 77, 27, 4096, seed=3)
+    elif kind == "banded_narrow":
+        A = P.banded_random(140000, 27, 1000, seed=5)
+    elif kind == "laplace7":
+        A = P.laplace7(50, 50, 60)
+    else:
+        m = 120000
+        lens = g.integers(0, 22, m)
+        lens[::53] = 0
+        rowptr = np.zeros(m + 1, dtype=np.int64)
+        rowptr[1:] = np.cumsum(lens)
+        col = np.concatenate([np.sort(g.integers(max(0, i - 3000), min(m, i + 3000), n)) for i, n in enumerate(lens)]).astype(np.int32)
+        A = (rowptr, col, g.uniform(-1, 1, col.size))
+    m = A[0].size - 1
+    op = rails_amd.HipOperatorWrapper(ctx, *A)
+    Xh, X, Y, outp = _panels(ctx, m, nc, seed=nc + 3)
+    op.set_variant(7)
+    op.apply(X, Y)
+    assert op.last_kernel() == "k_spmm_sweep"
+    Ys = Y.to_host()
+    op.set_variant(3)
+    op.apply(X, Y)
+    assert op.last_kernel() == "k_spmm_rowgather"
+    assert np.array_equal(Ys, Y.to_host())

@@ -32,22 +32,25 @@ def _check(oracle, A, params, n_chunks, ncols=None, seed=0):
     return pl
 
 
+@pytest.mark.parametrize("entry_trips", [4, 2])
 @pytest.mark.parametrize("waves,groups,seg,phases", [(1, 4, 8, 4), (2, 10, 16, 2), (3, 5, 16, 3), (2, 6, 32, 4)])
-def test_banded_small_geometries(oracle, waves, groups, seg, phases):
+def test_banded_small_geometries(oracle, waves, groups, seg, phases, entry_trips):
     bw = 7 * seg // 2
     R = waves * groups * 16
     assert (phases - 1) * R >= 2 * bw + 1 + seg  # the feasibility rule of sweep_plan.h
     A = P.banded_random(5 * phases * R + 37, 9, bw, seed=waves + groups)
-    pl = _check(oracle, A, (waves, groups, seg, 5, 3, phases), 2)
-    assert 0.2 < pl.efficiency <= 1.0
+    pl = _check(oracle, A, (waves, groups, seg, 5, 3, phases, 1, entry_trips), 2)
+    assert pl.entry_trips == entry_trips and 0.2 < pl.efficiency <= 1.0
 
 
-def test_kernel_geometry_on_the_bench_pattern(oracle):
-    # the kernel's own geometry (8 waves x 22 groups of 16 rows, 256-row steps, 5 segments, 8 parts x 4 phases) at 1/8 of the bench size
+@pytest.mark.parametrize("entry_trips", [4, 2])
+def test_kernel_geometry_on_the_bench_pattern(oracle, entry_trips):
+    # the kernel's own geometry (8 waves x 22 groups of 16 rows, 256-row steps, 5 segments, 8 parts x 4 phases) at 1/8 of the bench size;
+    # entries of half a unit (two trips) waste fewer slots than whole units
     A = P.banded_random(131072, 27, 4096, seed=1)
-    pl = _check(oracle, A, None, 8)
-    assert (pl.waves, pl.groups, pl.seg_rows, pl.nseg, pl.parts, pl.phases, pl.slots) == (8, 22, 256, 5, 8, 4, 16)
-    assert pl.efficiency > 0.5
+    pl = _check(oracle, A, (8, 22, 256, 5, 8, 4, 1, entry_trips), 8)
+    assert (pl.waves, pl.groups, pl.seg_rows, pl.nseg, pl.parts, pl.phases, pl.slots, pl.entry_trips) == (8, 22, 256, 5, 8, 4, 16, entry_trips)
+    assert pl.efficiency > (0.5 if entry_trips == 4 else 0.6)
 
 
 def test_ragged_rows_empty_rows_duplicates_and_rectangular(oracle):
@@ -63,6 +66,7 @@ def test_ragged_rows_empty_rows_duplicates_and_rectangular(oracle):
     col = np.concatenate(rows).astype(np.int32)
     val = g.uniform(-1, 1, col.size)
     _check(oracle, (rowptr, col, val), (2, 10, 16, 5, 4, 4), 1, ncols=ncols)
+    _check(oracle, (rowptr, col, val), (2, 10, 16, 5, 4, 4, 1, 2), 1, ncols=ncols)
 
 
 def test_long_rows_and_single_part(oracle):
@@ -75,6 +79,7 @@ def test_long_rows_and_single_part(oracle):
     col = np.concatenate(rows).astype(np.int32)
     val = g.uniform(-1, 1, col.size)
     _check(oracle, (rowptr, col, val), (1, 8, 16, 5, 1, 4), 2)
+    _check(oracle, (rowptr, col, val), (1, 8, 16, 5, 1, 4, 1, 2), 2)
 
 
 def test_tiny_and_empty_matrices(oracle):
