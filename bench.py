@@ -244,7 +244,7 @@ def main():
         A.apply(X, Y)
     spmm_ms = ctx.timer_stop() / args.spmm_reps
     spmm_kernel = A.last_kernel()
-    sweep_stats = A.sweep_stats(kk) if spmm_kernel == "k_spmm_sweep" else None
+    sweep_stats = A.sweep_stats(kk) if spmm_kernel.startswith("k_spmm_sweep") else None
     # algorithmic bytes per launch: nnz*(8+4) + (m+1)*4 + 2*m*k*8
     alg_bytes = nnz_local * 12 + (ml + 1) * 4 + 2 * ml * kk * 8
     achieved = alg_bytes / (spmm_ms * 1e-3) / 1e9

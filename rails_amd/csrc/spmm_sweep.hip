@@ -377,7 +377,7 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
         break;
     }
     RAILS_HIP_CHECK(hipGetLastError());
-    A->last_kernel = "k_spmm_sweep";
+    A->last_kernel = d->host.p.entry_trips == 2 ? "k_spmm_sweep_h2" : "k_spmm_sweep";
     c->n_spmm_sweep++;
     *done = true;
     return RAILS_OK;

@@ -11,7 +11,7 @@
 //     orthonormalise the tail against P: block CGS2 + CholQR2, coefficients by bookkeeping) and `random()` (fill, project);
 //   * after a restart the live coefficient matrices span fewer directions than P holds: compress() re-bases P on an
 //     orthonormal basis of their column space (pivoted Householder QR on the host, one panel GEMM on the device).
-// Per RAILS trip that is ~5 passes over the m x dim basis (materialise W, two rounds of Gram + update; the Lanczos start vector of
+// Per RAILS trip that is 4 passes over the m x dim basis (materialise W, first Gram, update + second Gram fused, second update; the Lanczos start vector of
 // the next trip rides in the A*W block) instead of the 21 passes over [AV V B] of the fused Lanczos kernel plus the projection /
 // orthogonalisation passes of the direct back end (HipWrappers.hpp), and 5 all-reduces instead of ~31.
 //

@@ -63,7 +63,7 @@ def test_spmm_full_size(ctx, oracle, c3):
     X.random()
     assert op.prepare(128)  # set-up for repeated products of this width (rails_csr_prepare): the sweep kernel's schedule
     Y = op.apply(X)
-    assert op.last_kernel() == "k_spmm_sweep"  # banded pattern at panel width: the sweep kernel (spmm_sweep.hip) is the automatic choice
+    assert op.last_kernel().startswith("k_spmm_sweep")  # banded pattern at panel width: the sweep kernel (spmm_sweep.hip) is the automatic choice
     Xh = X.to_host()
     rows = np.unique(np.concatenate([np.arange(0, 64), np.arange(m - 64, m), g.integers(0, m, 4000)]))
     Yh = Y.to_host()

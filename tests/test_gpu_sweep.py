@@ -42,7 +42,7 @@ def test_sweep_is_bitwise_the_rowgather_result_and_matches_the_oracle(ctx, oracl
     outp.assign(0.0)
     op.set_variant(7)
     op.apply(X, Y)
-    assert op.last_kernel() == "k_spmm_sweep"
+    assert op.last_kernel().startswith("k_spmm_sweep")
     st = op.sweep_stats(nc)
     assert st["built"] and st["efficiency"] > 0.5
     Ys = Y.to_host()
@@ -83,7 +83,7 @@ def test_sweep_on_stencils_and_at_256_columns(ctx, kind, nc):
     Xh, X, Y, outp = _panels(ctx, m, nc, seed=nc + 1)
     op.set_variant(7)
     op.apply(X, Y)
-    assert op.last_kernel() == "k_spmm_sweep"
+    assert op.last_kernel().startswith("k_spmm_sweep")
     Ys = Y.to_host()
     op.set_variant(3)
     op.apply(X, Y)
@@ -163,9 +163,9 @@ def test_auto_choice_on_the_bench_matrix_and_its_transpose(ctx):
     Y0 = op.apply(X)
     for _ in range(14):
         op.apply(X, Y0)
-    assert op.last_kernel() != "k_spmm_sweep" and not op.sweep_stats(128)["built"]
+    assert not op.last_kernel().startswith("k_spmm_sweep") and not op.sweep_stats(128)["built"]
     Y = op.apply(X)
-    assert op.last_kernel() == "k_spmm_sweep" and op.sweep_stats(128)["built"]
+    assert op.last_kernel().startswith("k_spmm_sweep") and op.sweep_stats(128)["built"]
     d0 = Y.copy()
     d0 -= Y0
     assert d0.norm() <= 1e-13 * Y.norm()
@@ -186,7 +186,7 @@ def test_auto_choice_on_the_bench_matrix_and_its_transpose(ctx):
     At = op.transpose()
     assert At.prepare(128)
     AtZ = At.apply(Z)
-    assert op.last_kernel() == "k_spmm_sweep"
+    assert op.last_kernel().startswith("k_spmm_sweep")
     rhs = AtZ.dot(X)
     assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(lhs).max()
 
@@ -206,7 +206,7 @@ def test_auto_leaves_structured_stencils_to_the_box_kernel(ctx):
     assert op.last_kernel() == "k_spmm_tiled_reg"
     op.set_variant(7)
     Ys = op.apply(X)
-    assert op.last_kernel() == "k_spmm_sweep"
+    assert op.last_kernel().startswith("k_spmm_sweep")
     d = Y.copy()
     d -= Ys
     assert d.norm() <= 1e-13 * Y.norm()  # (the box kernel adds a row's terms in its own order)
@@ -243,7 +243,7 @@ def test_both_entry_sizes_are_bitwise_the_rowgather_result(ctx, monkeypatch, kin
     Xh, X, Y, outp = _panels(ctx, m, nc, seed=nc + 3)
     op.set_variant(7)
     op.apply(X, Y)
-    assert op.last_kernel() == "k_spmm_sweep"
+    assert op.last_kernel() == ("k_spmm_sweep_h2" if entry_trips == 2 else "k_spmm_sweep")
     Ys = Y.to_host()
     op.set_variant(3)
     op.apply(X, Y)
