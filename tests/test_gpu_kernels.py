@@ -205,7 +205,8 @@ def test_csr_create_rejects_bad_indices(ctx):
 @pytest.mark.parametrize("m", [1, 63, 1000, 20011])
 def test_gram_matches_oracle(ctx, oracle, m):
     g = np.random.default_rng(m)
-    for a, b in ((1, 1), (3, 5), (16, 16), (40, 8), (130, 16), (16, 130), (64, 33), (17, 1)):
+    # (130 x 17, 367 x 17: the first Gram matrix of an A*W block with its 17th column, k_gram_cols<TI, 2>)
+    for a, b in ((1, 1), (3, 5), (16, 16), (40, 8), (130, 16), (16, 130), (64, 33), (17, 1), (130, 17), (367, 17), (200, 18), (150, 20)):
         Xh = g.uniform(-1, 1, (m, a))
         Yh = g.uniform(-1, 1, (m, b))
         X, Y = MV(ctx, Xh), MV(ctx, Yh)
