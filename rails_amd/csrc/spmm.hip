@@ -232,10 +232,11 @@ __global__ __launch_bounds__(256) void k_spmm_rowgather_cc(int64_t m, const int6
 // 24-bit multiply-add for the byte offset, one 16-byte load with a scalar base, two multiply-adds.  Kernel 1b spends ~37 vector
 // instructions per nonzero on 64-bit addresses, the ghost-row select and the masks of its tail and ran at the instruction rate
 // (rocprofv3 --pmc: 2000 VALU instructions per wave of 16 rows, TA and L2 far from busy): 0.40 ms at 16 columns, 18 % of the HBM rate.
-template <int RPG>
+template <int RPG, bool GHOST>
 __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                      const double *__restrict__ val, const double *__restrict__ X, uint32_t ldx8,
-                                                     double *__restrict__ Y, int ldy, int nc, int64_t blocks_per_xcd, int y_vec)
+                                                     const double *__restrict__ Xg, uint32_t ldg8, double *__restrict__ Y, int ldy, int nc,
+                                                     int64_t blocks_per_xcd, int y_vec)
 {
     constexpr int LPR = 8, GROUPS = 256 / LPR, ROWS = GROUPS * RPG, CAP = 2048;
     __shared__ double s_val[CAP];
@@ -258,8 +259,15 @@ __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *_
     const int cb = l * 2;
     if (cb >= nc) return;
     const bool full = (cb + 2 <= nc);
-    const uint32_t cb8 = (uint32_t)cb * 8u;
-    const char *Xb = reinterpret_cast<const char *>(X);
+    const uint32_t cb8 = (uint32_t)cb * 8u, m32 = (uint32_t)m;
+    const char *Xb = reinterpret_cast<const char *>(X), *Gb = reinterpret_cast<const char *>(Xg);
+    // the address of this lane's two columns of X row c: local rows from the panel, ghost rows (c >= m, row-partitioned runs) from the
+    // buffer the halo exchange filled -- a select between two bases and two strides, still 32-bit offsets
+    auto xrow = [&](uint32_t c) -> const char * {
+        if (!GHOST) return Xb + (__umul24(c, ldx8) + cb8);
+        const bool local = c < m32;
+        return (local ? Xb : Gb) + ((local ? __umul24(c, ldx8) : __umul24(c - m32, ldg8)) + cb8);
+    };
     for (int rr = 0; rr < RPG; ++rr) {
         const int64_t row = r0 + (int64_t)rr * GROUPS + g; // the 32 rows in flight are consecutive
         if (row >= m) break;
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *_
                 double a[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    x[u] = *reinterpret_cast<const double2_t *>(Xb + (__umul24((uint32_t)s_col[i + u], ldx8) + cb8));
+                    x[u] = *reinterpret_cast<const double2_t *>(xrow((uint32_t)s_col[i + u]));
                     a[u] = s_val[i + u];
                 }
 #pragma unroll
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *_
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int q = i + u < i1 ? i + u : i1 - 1;
-                    x[u] = *reinterpret_cast<const double2_t *>(Xb + (__umul24((uint32_t)s_col[q], ldx8) + cb8));
+                    x[u] = *reinterpret_cast<const double2_t *>(xrow((uint32_t)s_col[q]));
                     a[u] = i + u < i1 ? s_val[q] : 0.0;
                 }
 #pragma unroll
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *_
             // (a block with more nonzeros than the LDS buffer holds, or the lane of an odd last column: one entry at a time)
             for (int64_t p = rowptr[row]; p < rowptr[row + 1]; ++p) {
                 const double a = val[p];
-                const double *src = reinterpret_cast<const double *>(Xb + (__umul24((uint32_t)col[p], ldx8) + cb8));
+                const double *src = reinterpret_cast<const double *>(xrow((uint32_t)col[p]));
                 acc.x = __builtin_fma(a, src[0], acc.x);
                 if (full) acc.y = __builtin_fma(a, src[1], acc.y);
             }
@@ -335,9 +343,18 @@ int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, con
         // every X row at X + c * ldx (no ghost rows; a rectangular operator's extra rows follow X in the same panel) within 32-bit byte offsets
         static const int narrow_fast = spmm_env("RAILS_SPMM_NARROW_FAST", 1);
         const bool flat = (A->n_ghost == 0 && !A->rect) || (Xg == X + (int64_t)A->m * ldx && ldg == ldx);
-        if (narrow_fast && flat && A->ncols_ext < (1 << 24) && (int64_t)ldx * 8 < (1 << 24) && (uint64_t)A->ncols_ext * (uint64_t)ldx * 8u < 0xffffff00ull) {
-            RAILS_LAUNCH((k_spmm_narrow<RPG>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, Y, ldy, nc, bpx,
-                         y_vec ? 1 : 0);
+        const bool small = A->ncols_ext < (1 << 24) && (int64_t)ldx * 8 < (1 << 24) && (int64_t)ldg * 8 < (1 << 24);
+        if (narrow_fast && small && flat && (uint64_t)A->ncols_ext * (uint64_t)ldx * 8u < 0xffffff00ull) {
+            RAILS_LAUNCH((k_spmm_narrow<RPG, false>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, X, 0u, Y,
+                         ldy, nc, bpx, y_vec ? 1 : 0);
+            if (kernel) *kernel = "k_spmm_narrow";
+            return RAILS_OK;
+        }
+        // row-partitioned runs: columns >= m are ghost rows in the halo buffer (16-byte aligned rows there too)
+        if (narrow_fast && small && !flat && !A->rect && (uint64_t)A->m * (uint64_t)ldx * 8u < 0xffffff00ull &&
+            (uint64_t)(A->ncols_ext - A->m) * (uint64_t)ldg * 8u < 0xffffff00ull && (((uintptr_t)Xg) & 15) == 0 && ldg % 2 == 0) {
+            RAILS_LAUNCH((k_spmm_narrow<RPG, true>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, Xg,
+                         (uint32_t)ldg * 8u, Y, ldy, nc, bpx, y_vec ? 1 : 0);
             if (kernel) *kernel = "k_spmm_narrow";
             return RAILS_OK;
         }

@@ -137,6 +137,8 @@ def test_partitioned_spmm_and_reductions(oracle, nranks):
         for nc in (24, 16, 3):
             Y = op.apply(MV(ctx, data=X[r0:r1, :nc]))
             out["Y%d" % nc] = Y.to_host()
+            if nc == 16:
+                out["kernel16"] = op.last_kernel()  # the in-loop width: the lean kernel in its ghost-row form (spmm.hip kernel 1c)
         Xl = MV(ctx, data=X[r0:r1])
         out["gram"] = Xl.view(0, 7).dot(Xl.view(8, 23))  # all-reduced over the ranks
         Rn = MV(ctx, m=r1 - r0, n=3, capacity=4)
@@ -153,7 +155,7 @@ def test_partitioned_spmm_and_reductions(oracle, nranks):
         assert np.abs(Y - ref).max() <= 1e-13 * np.abs(ref).max()
     G = X[:, :8].T @ X[:, 8:]
     for r in range(nranks):
-        assert res[r]["ghosts"] > 0
+        assert res[r]["ghosts"] > 0 and res[r]["kernel16"] == "k_spmm_narrow"
         np.testing.assert_allclose(res[r]["gram"], G, atol=1e-11)
         assert np.array_equal(res[r]["gram"], res[0]["gram"])  # replicated small objects are bit-identical on every rank
     assert np.array_equal(np.vstack([res[r]["rand"] for r in range(nranks)]), oracle.random(m, 3, mode=1, seed=5, stream=0))
