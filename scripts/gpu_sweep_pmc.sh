@@ -3,14 +3,14 @@
 # Default: the sweep kernel at 128 columns; COLS=16 VAR=0 PAD=1 TAG=narrow_pmc looks at the in-loop 16-column product.
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-COLS=${COLS:-128}; VAR=${VAR:-7}; PAD=${PAD:-0}; TAG=${TAG:-sweep_pmc}
+COLS=${COLS:-128}; VAR=${VAR:-7}; PAD=${PAD:-0}; TAG=${TAG:-sweep_pmc}; PATTERN=${PATTERN:-banded}
 export PMC_TAG=$TAG
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   name=$1; shift
-  timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $O/$name -- python3 $R/bench.py --spmm-only --pattern banded --spmm-cols $COLS --spmm-variant $VAR --spmm-pad $PAD --spmm-reps 3 > $O/$name.json 2> $O/$name.err || { tail -3 $O/$name.err; return 1; }
+  timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $O/$name -- python3 $R/bench.py --spmm-only --pattern $PATTERN --spmm-cols $COLS --spmm-variant $VAR --spmm-pad $PAD --spmm-reps 3 > $O/$name.json 2> $O/$name.err || { tail -3 $O/$name.err; return 1; }
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA &&
 run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM &&
