@@ -64,6 +64,13 @@ struct GroupRun {
         bj = ph;
         loaded = false;
         need = full = 0;
+        // room for the slots this group is going to fill (its rows' nonzeros at about half-full trips): growing by doubling copies and
+        // faults in twice the memory
+        const int64_t rows = (c->r1 - c->r0 + c->prm->phases * c->prm->waves * c->prm->groups - 1) / ((int64_t)c->prm->phases * c->prm->waves * c->prm->groups);
+        const double per_row = c->r1 > c->r0 ? (double)(c->rowptr[c->r1] - c->rowptr[c->r0]) / (double)(c->r1 - c->r0) : 0.0;
+        const size_t guess = (size_t)((double)rows * per_row * 2.2) + 64;
+        out.val.reserve(guess);
+        out.off.reserve(guess);
     }
 
     void load_block(int64_t j)
@@ -451,6 +458,14 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
         for (std::thread &t : pool) t.join();
     }
     int64_t staged = 0;
+    {
+        size_t nc = 0, nv = 0, nf = 0;
+        for (int x = 0; x < prm.parts; ++x) nc += piece[x].codes.size(), nv += piece[x].vals.size(), nf += piece[x].flush_rows.size();
+        plan.codes.reserve(nc);
+        plan.vals.reserve(nv + 8 * 256);
+        plan.offs.reserve(nv + 8 * 256);
+        plan.flush_rows.reserve(nf);
+    }
     for (int x = 0; x < prm.parts; ++x) {
         rails_sweep_plan &q = piece[x];
         if (!piece_ok[x]) {
