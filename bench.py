@@ -249,6 +249,23 @@ def main():
     alg_bytes = nnz_local * 12 + (ml + 1) * 4 + 2 * ml * kk * 8
     achieved = alg_bytes / (spmm_ms * 1e-3) / 1e9
     del X, Y
+    # the product the solver's loop does every trip: A * W at Expand size columns, W behind an odd-sized panel stride as in the solver
+    ke = args.expand
+    Xe = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=ke, capacity=ke + 1)
+    Ye = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=ke, capacity=ke + 1)
+    Xe.random()
+    for _ in range(3):
+        A.apply(Xe, Ye)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(args.spmm_reps):
+        A.apply(Xe, Ye)
+    inloop_ms = ctx.timer_stop() / args.spmm_reps
+    inloop_bytes = nnz_local * 12 + (ml + 1) * 4 + 2 * ml * ke * 8
+    inloop = {"kernel": A.last_kernel(), "columns": ke, "avg_ms": inloop_ms, "algorithmic_bytes": inloop_bytes,
+              "frac": inloop_bytes / (inloop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    log("[rank %d] in-loop SpMM %s k=%d: %.3f ms (%.1f%% of %.0f GB/s)" % (rank, inloop["kernel"], ke, inloop_ms, 100 * inloop["frac"], HBM_PEAK_GBS))
+    del Xe, Ye
     traffic = None
     traffic_stale = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -441,7 +458,7 @@ def main():
                                    "Expand size %d, Lanczos iterations %d" % (ml, mg, desc, args.p, args.restart, args.reduced, args.expand, args.lanczos),
                        "parallelism": "row-partition x%d, RCCL all-reduce of projected blocks" % nranks if nranks > 1 else "single GPU",
                        "collectives": collectives,
-                       "spmm_columns": kk, "residual_lanczos": ("the reference's recurrence on coordinate vectors (host)" if args.subspace else
+                       "spmm_columns": kk, "inloop_spmm": inloop, "residual_lanczos": ("the reference's recurrence on coordinate vectors (host)" if args.subspace else
                                             ("coefficient-space, Gram differences" if args.projected_lanczos else "fused one-pass-per-step kernel")),
                        "backend": "coordinates in a device-resident orthonormal basis" if args.subspace else "direct panels",
                        # one JOINT solve over n_gpus x m rows: under weak scaling the ideal is a constant iteration rate; the rate at which
