@@ -148,8 +148,8 @@ int rails_spmm(rails_ctx *ctx, rails_csr *A, int trans, const rails_panel *X, in
  * pattern or the column count does not fit), 8 = never the sweep kernel (auto otherwise). */
 int rails_csr_set_variant(rails_csr *A, int variant);
 /* Set-up for products of nc columns with A (trans != 0: with its transpose): builds now what the automatic kernel choice would
- * otherwise put off -- the sweep kernel's schedule (banded patterns, 64 to 256 columns) costs about half a second of host time per million
- * rows, several hundred times what it saves one product, so without this call an operator only builds it after it has been asked for
+ * otherwise put off -- the sweep kernel's schedule (banded patterns, 64 to 256 columns) costs about a third of a second of host time per
+ * million rows, a few hundred times what it saves one product, so without this call an operator only builds it after it has been asked for
  * RAILS_SWEEP_AFTER (default 16) products of that width.  *kernel_ready (may be null) = 1 when the sweep kernel will take them.  A
  * no-op for operators and widths the kernel does not apply to.  The reference has no counterpart: Epetra's FillComplete is the
  * nearest (set-up work of the matrix class before `A_ * W`, src/LyapunovSolver.hpp:146). */

@@ -17,9 +17,35 @@ constexpr int SLOTS = 16; // rows of a group in one wave: a slot is a quad of la
 struct GroupSchedule {
     std::vector<int> step;        // per unit: the step it runs in
     std::vector<uint8_t> flags;   // per unit: 1 = the group's partial sums go to Y afterwards, 2 = no trips
-    std::vector<double> val;      // [units with trips][entry_trips][SLOTS]
-    std::vector<uint16_t> off;
     std::vector<int32_t> flush;   // first row of the wave's slot octet, per flush, in order
+};
+
+// The (value, ring row) pairs of one wave, in the order and layout in which the kernel consumes them: the groups of a wave are run
+// group by group within a step and step by step (schedule_part), which is the order of the wave's entries in its records, so every
+// trip goes straight to its place -- no per-group copy to be gathered later (a cold build is bound by the memory it touches).
+// Trip tt of a batch of 16 = unit tt / 4, quad lane tt % 4: lane (slot, quad lane) holds four values, one per unit -- units 0, 1 in
+// the first KiB of the batch, 2, 3 in the second (one 16-byte load each) -- and four 16-bit ring rows (one 8-byte load).
+struct WaveStream {
+    std::vector<double> vals;
+    std::vector<uint16_t> offs;
+    int64_t trip = 0;
+    void emit(const double *v, const int64_t *o, int ring)
+    {
+        const int64_t b = trip / 16;
+        if ((size_t)(b + 1) * 256 > vals.size()) {
+            vals.resize((size_t)(b + 1) * 256, 0.0);
+            offs.resize((size_t)(b + 1) * 256, 0);
+        }
+        const int tt = (int)(trip % 16), unit = tt / 4, ql = tt % 4;
+        double *vb = vals.data() + (size_t)b * 256 + (size_t)(unit / 2) * 128 + (unit % 2);
+        uint16_t *ob = offs.data() + (size_t)b * 256 + unit;
+        for (int s = 0; s < SLOTS; ++s) {
+            const size_t lane = (size_t)s * 4 + ql;
+            vb[lane * 2] = v[s];
+            ob[lane * 4] = (uint16_t)(o[s] % ring);
+        }
+        ++trip;
+    }
 };
 
 struct Ctx {
@@ -41,6 +67,7 @@ struct GroupRun {
     const Ctx *c = nullptr;
     int phase = 0, wave = 0, g = 0;
     GroupSchedule out;
+    WaveStream *stream = nullptr;  // the wave's stream of (value, ring row) pairs
     int64_t bj = 0;                // current block of this workgroup
     int64_t p[SLOTS], pe[SLOTS];   // next / end nonzero of each slot's row
     int64_t last_pos[SLOTS];
@@ -64,13 +91,6 @@ struct GroupRun {
         bj = ph;
         loaded = false;
         need = full = 0;
-        // room for the slots this group is going to fill (its rows' nonzeros at about half-full trips): growing by doubling copies and
-        // faults in twice the memory
-        const int64_t rows = (c->r1 - c->r0 + c->prm->phases * c->prm->waves * c->prm->groups - 1) / ((int64_t)c->prm->phases * c->prm->waves * c->prm->groups);
-        const double per_row = c->r1 > c->r0 ? (double)(c->rowptr[c->r1] - c->rowptr[c->r0]) / (double)(c->r1 - c->r0) : 0.0;
-        const size_t guess = (size_t)((double)rows * per_row * 2.2) + 64;
-        out.val.reserve(guess);
-        out.off.reserve(guess);
     }
 
     void load_block(int64_t j)
@@ -201,9 +221,8 @@ struct GroupRun {
                         last_pos[s] = o[t][s];
                     else
                         o[t][s] = (last_pos[s] >= 0 && last_pos[s] >= lo) ? last_pos[s] : first_real;
-                    out.val.push_back(v[t][s]);
-                    out.off.push_back((uint16_t)(o[t][s] % ring));
                 }
+            for (int t = 0; t < UT; ++t) stream->emit(v[t], o[t], ring);
             out.step.push_back(k);
             out.flags.push_back(0);
         }
@@ -238,13 +257,23 @@ struct GroupRun {
 // quarters of a unit's time), so that an X row fetched by one of them is still in the L2 when the others ask for it (left alone they drift apart by more
 // steps than the L2 holds: 3.9 GB fetched per product instead of 1.7 GB).  Costs no time: the product takes as long as its slowest
 // workgroup either way.  runs[phase * W + wave][group].
-bool schedule_part(const Ctx &c, std::vector<std::vector<GroupRun>> &runs, std::vector<int> &pause, std::string &why)
+bool schedule_part(const Ctx &c, std::vector<std::vector<GroupRun>> &runs, std::vector<WaveStream> &streams, std::vector<int> &pause, std::string &why)
 {
     const rails_sweep_params &P = *c.prm;
     const int W = P.waves, G = P.groups, NW = P.phases * W, UT = P.entry_trips;
     const int cap = RAILS_SWEEP_CODES - 2;
-    for (int x = 0; x < NW; ++x)
-        for (int g = 0; g < G; ++g) runs[x][g].start(c, x / W, x % W, g);
+    // room for a wave's stream: its rows' nonzeros at trips about half full (growing by doubling copies and faults in twice the memory)
+    const double per_row = c.r1 > c.r0 ? (double)(c.rowptr[c.r1] - c.rowptr[c.r0]) / (double)(c.r1 - c.r0) : 0.0;
+    const size_t guess = (size_t)((double)(c.r1 - c.r0) / NW * per_row * 2.0) + 4096;
+    for (int x = 0; x < NW; ++x) {
+        streams[x] = WaveStream();
+        streams[x].vals.reserve(guess);
+        streams[x].offs.reserve(guess);
+        for (int g = 0; g < G; ++g) {
+            runs[x][g].start(c, x / W, x % W, g);
+            runs[x][g].stream = &streams[x];
+        }
+    }
     std::vector<int> units((size_t)NW * G), load(NW);
     pause.assign((size_t)P.phases * c.nsteps, 0);
     std::vector<int64_t> spent(P.phases, 0); // units of the busiest wave, summed over the steps so far: the workgroup's time
@@ -340,9 +369,10 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
             }
     // The parts are independent: each is planned by a thread of its own into a plan of its own, and the pieces are joined afterwards.
     const std::vector<int64_t> part_row0 = plan.part_row0;
-    auto plan_part = [&](int x, rails_sweep_plan &plan, int64_t &staged) -> bool {
+    auto plan_part = [&](int x, rails_sweep_plan &plan, std::vector<WaveStream> &streams, int64_t &staged) -> bool {
         std::vector<std::vector<GroupRun>> runs((size_t)P * W, std::vector<GroupRun>(G));
         std::vector<int> pause;
+        streams.assign((size_t)P * W, WaveStream());
         Ctx c;
         c.prm = &prm;
         c.rowptr = rowptr;
@@ -367,20 +397,21 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
         plan.sweep0[x] = c.sweep0;
         plan.nsteps[x] = c.nsteps;
         staged += (int64_t)c.nsteps * SEG * P;
-        if (!schedule_part(c, runs, pause, plan.why)) return false; // (this part)
+        if (!schedule_part(c, runs, streams, pause, plan.why)) return false; // (this part)
+        int64_t batches = 0; // batches of 16 trips of the waves before this one
         for (int ph = 0; ph < P; ++ph) {
             for (int w = 0; w < W; ++w) {
                 const int64_t prog = ((int64_t)x * P + ph) * W + w;
                 std::vector<GroupRun> &gr = runs[(size_t)ph * W + w];
                 // serialise: per step a record of RAILS_SWEEP_CODES 32-bit entries (sweep_plan.h): a header with the number of entries, then
-                // one entry per unit of four trips (or per flush without trips), in group order; the trips in the same order
+                // one entry per unit (or per flush without trips), in group order; the trips are in the wave's stream in the same order
                 plan.hdr_off[prog] = (int64_t)plan.codes.size();
                 plan.codes.resize(plan.codes.size() + (size_t)c.nsteps * RAILS_SWEEP_CODES, 0u);
                 uint32_t *h = plan.codes.data() + plan.hdr_off[prog];
-                plan.batch_off[prog] = (int64_t)(plan.vals.size() / 256);
+                plan.batch_off[prog] = batches; // (within this part; the streams are joined afterwards)
                 plan.flush_off[prog] = (int64_t)plan.flush_rows.size();
-                std::vector<size_t> up(G, 0), tp(G, 0), fp(G, 0); // per group: next unit / next unit with trips / next flush
-                int64_t trip = 0;                                  // trips of this wave so far
+                std::vector<size_t> up(G, 0), fp(G, 0); // per group: next unit / next flush
+                int64_t trip = 0;                       // trips of this wave so far
                 for (int k = 0; k < c.nsteps; ++k) {
                     int n = 0;
                     uint32_t *rec = h + (size_t)k * RAILS_SWEEP_CODES;
@@ -392,25 +423,7 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                                 return false; // (this part)
                             }
                             rec[1 + n++] = (uint32_t)(g * 8) | ((fl & 1) ? RAILS_SWEEP_FLUSH : 0u) | ((fl & 2) ? RAILS_SWEEP_NO_TRIPS : 0u);
-                            if (!(fl & 2)) {
-                                for (int t = 0; t < prm.entry_trips; ++t, ++trip) {
-                                    const int64_t b = plan.batch_off[prog] + trip / 16;
-                                    if ((size_t)(b + 1) * 256 > plan.vals.size()) {
-                                        plan.vals.resize((size_t)(b + 1) * 256, 0.0);
-                                        plan.offs.resize((size_t)(b + 1) * 256, 0);
-                                    }
-                                    // trip tt of the batch = unit tt / 4, quad lane tt % 4: lane (slot, quad lane) holds four values, one per
-                                    // unit -- units 0, 1 in the first KiB of the batch, 2, 3 in the second (one 16-byte load each) -- and
-                                    // four 16-bit ring rows (one 8-byte load)
-                                    const int tt = (int)(trip % 16), unit = tt / 4, ql = tt % 4;
-                                    for (int s = 0; s < SLOTS; ++s) {
-                                        const size_t lane = (size_t)s * 4 + ql;
-                                        plan.vals[(size_t)b * 256 + (size_t)(unit / 2) * 128 + lane * 2 + (unit % 2)] = gr[g].out.val[(tp[g] * prm.entry_trips + t) * SLOTS + s];
-                                        plan.offs[(size_t)b * 256 + lane * 4 + unit] = gr[g].out.off[(tp[g] * prm.entry_trips + t) * SLOTS + s];
-                                    }
-                                }
-                                ++tp[g];
-                            }
+                            if (!(fl & 2)) trip += prm.entry_trips;
                             if (fl & 1) {
                                 // the rows the flush writes: sixteen from this one on, as a multiple of 16 from the part's first row in the entry
                                 const int64_t row = gr[g].out.flush[fp[g]++], rel = (row - c.r0) / 16;
@@ -429,12 +442,18 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                         if (rec[e] & RAILS_SWEEP_NO_TRIPS) rec[e - 1] |= RAILS_SWEEP_NEXT_NO_TRIPS;
                     plan.max_units_per_step = std::max(plan.max_units_per_step, n);
                 }
+                if (trip != streams[(size_t)ph * W + w].trip) {
+                    plan.why = "internal: the records of a wave do not add up to its stream";
+                    return false; // (this part)
+                }
                 plan.trips += trip;
+                batches += (trip + 15) / 16;
             }
         }
-            return true;
+        return true;
     };
     std::vector<rails_sweep_plan> piece(prm.parts);
+    std::vector<std::vector<WaveStream>> piece_streams(prm.parts);
     std::vector<int64_t> piece_staged(prm.parts, 0);
     std::vector<char> piece_ok(prm.parts, 0);
     {
@@ -449,7 +468,7 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
                 q.hdr_off.assign(nprog, 0);
                 q.batch_off.assign(nprog, 0);
                 q.flush_off.assign(nprog, 0);
-                piece_ok[x] = plan_part(x, q, piece_staged[x]) ? 1 : 0;
+                piece_ok[x] = plan_part(x, q, piece_streams[x], piece_staged[x]) ? 1 : 0;
             }
         };
         std::vector<std::thread> pool;
@@ -460,7 +479,10 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
     int64_t staged = 0;
     {
         size_t nc = 0, nv = 0, nf = 0;
-        for (int x = 0; x < prm.parts; ++x) nc += piece[x].codes.size(), nv += piece[x].vals.size(), nf += piece[x].flush_rows.size();
+        for (int x = 0; x < prm.parts; ++x) {
+            nc += piece[x].codes.size(), nf += piece[x].flush_rows.size();
+            for (WaveStream const &ws : piece_streams[x]) nv += (size_t)((ws.trip + 15) / 16) * 256;
+        }
         plan.codes.reserve(nc);
         plan.vals.reserve(nv + 8 * 256);
         plan.offs.reserve(nv + 8 * 256);
@@ -481,8 +503,12 @@ bool rails_sweep_plan_build(const rails_sweep_params &prm, int64_t m, int64_t nc
         plan.sweep0[x] = q.sweep0[x];
         plan.nsteps[x] = q.nsteps[x];
         plan.codes.insert(plan.codes.end(), q.codes.begin(), q.codes.end());
-        plan.vals.insert(plan.vals.end(), q.vals.begin(), q.vals.end());
-        plan.offs.insert(plan.offs.end(), q.offs.begin(), q.offs.end());
+        for (WaveStream &ws : piece_streams[x]) { // whole batches: a wave's next batch starts at a batch boundary
+            const size_t n = (size_t)((ws.trip + 15) / 16) * 256;
+            plan.vals.insert(plan.vals.end(), ws.vals.begin(), ws.vals.begin() + n);
+            plan.offs.insert(plan.offs.end(), ws.offs.begin(), ws.offs.begin() + n);
+            ws = WaveStream();
+        }
         plan.flush_rows.insert(plan.flush_rows.end(), q.flush_rows.begin(), q.flush_rows.end());
         plan.trips += q.trips;
         plan.max_units_per_step = std::max(plan.max_units_per_step, q.max_units_per_step);
