@@ -19,6 +19,7 @@
 namespace {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double2_t double2_a8_t __attribute__((aligned(8))); // 16-byte loads of two doubles that are only 8-byte aligned (odd column offsets)
 
 template <int VEC>
 struct Acc;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *_
                 double a[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    x[u] = *reinterpret_cast<const double2_t *>(xrow((uint32_t)s_col[i + u]));
+                    x[u] = *reinterpret_cast<const double2_a8_t *>(xrow((uint32_t)s_col[i + u]));
                     a[u] = s_val[i + u];
                 }
 #pragma unroll
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *_
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int q = i + u < i1 ? i + u : i1 - 1;
-                    x[u] = *reinterpret_cast<const double2_t *>(xrow((uint32_t)s_col[q]));
+                    x[u] = *reinterpret_cast<const double2_a8_t *>(xrow((uint32_t)s_col[q]));
                     a[u] = i + u < i1 ? s_val[q] : 0.0;
                 }
 #pragma unroll
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *_
 
 template <int LPR>
 int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool y_vec = true,
-                 const char **kernel = nullptr)
+                 const char **kernel = nullptr, bool narrow_only = false)
 {
     if (kernel) *kernel = "k_spmm_rowgather_cc";
     constexpr int GROUPS = 256 / LPR;
@@ -352,12 +353,16 @@ int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, con
         }
         // row-partitioned runs: columns >= m are ghost rows in the halo buffer (16-byte aligned rows there too)
         if (narrow_fast && small && !flat && !A->rect && (uint64_t)A->m * (uint64_t)ldx * 8u < 0xffffff00ull &&
-            (uint64_t)(A->ncols_ext - A->m) * (uint64_t)ldg * 8u < 0xffffff00ull && (((uintptr_t)Xg) & 15) == 0 && ldg % 2 == 0) {
+            (uint64_t)(A->ncols_ext - A->m) * (uint64_t)ldg * 8u < 0xffffff00ull ) {
             RAILS_LAUNCH((k_spmm_narrow<RPG, true>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, Xg,
                          (uint32_t)ldg * 8u, Y, ldy, nc, bpx, y_vec ? 1 : 0);
             if (kernel) *kernel = "k_spmm_narrow";
             return RAILS_OK;
         }
+    }
+    if (narrow_only) { // nothing launched: the caller goes on to the plain row-gather kernel
+        if (kernel) *kernel = nullptr;
+        return RAILS_OK;
     }
     RAILS_LAUNCH((k_spmm_rowgather_cc<LPR, RPG>), dim3((unsigned)grid), dim3(256), (size_t)lds_cap * 12, c->stream, A->m, A->rowptr,
                        A->col, A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx, lds_cap, y_vec ? 1 : 0);
@@ -720,9 +725,19 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         const bool x_vec2 = (xc0 & 1) == 0 && (X->ld % 2 == 0) && (ldg % 2 == 0);
         const bool y_vec2 = (yc0 & 1) == 0 && (Y->ld % 2 == 0);
         if (cc == 0 && x_vec2 && narrow_env && A->variant != 3 && nc > 8 && nc <= (narrow_env == 2 ? 32 : 16) && A->max_row_nnz <= 64) cc = nc <= 16 ? 16 : -32;
+        // X rows that are only 8-byte aligned (a window on an odd column: A*W of the direct back end, W a view of V): kernel 1c loads its
+        // two doubles with one 16-byte instruction all the same (global memory asks for dword alignment); kernel 1b does not take them
+        bool narrow_only = false;
+        if (cc == 0 && !x_vec2 && narrow_env && A->variant != 3 && nc > 8 && nc <= 16 && A->max_row_nnz <= 64) cc = 16, narrow_only = true;
         const char *cc_kernel = "k_spmm_rowgather_cc";
-        if (cc == 16)
-            RAILS_TRY((launch_rg_cc<8>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, y_vec2, &cc_kernel)));
+        bool launched = false;
+        if (cc == 16) {
+            RAILS_TRY((launch_rg_cc<8>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, y_vec2, &cc_kernel, narrow_only)));
+            launched = cc_kernel != nullptr;
+            if (!launched) cc = 0; // (declined: kernel 1c does not apply and kernel 1b needs 16-byte aligned rows)
+        }
+        if (launched)
+            ;
         else if (cc == -32)
             RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, y_vec2)));
         else if (cc == 32)
