@@ -711,7 +711,12 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         RAILS_TRY(rails_spmm_sweep(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, al, A->variant == 7, &done));
         if (done) return RAILS_OK;
     }
-    if (A->variant == 0 || A->variant == 2 || A->variant == 6) RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, vec2, X->ld - xc0, &done));
+    // at Expand size <= 16 the lean row kernel (1c) beats the LDS-staged box kernel on the stencils too (27-point: 0.206 against 0.256 ms,
+    // 7-point: 0.097 against 0.130): in automatic mode the box kernel is for wider panels
+    static const int narrow_first = spmm_env("RAILS_SPMM_NARROW_CC", 1) && spmm_env("RAILS_SPMM_NARROW_FAST", 1);
+    const bool leave_to_narrow = A->variant == 0 && narrow_first && nc > 8 && nc <= 16 && A->max_row_nnz <= 64 && A->ncols_ext < (1 << 24);
+    if ((A->variant == 0 && !leave_to_narrow) || A->variant == 2 || A->variant == 6)
+        RAILS_TRY(rails_spmm_tiled(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, vec2, X->ld - xc0, &done));
     if (done) c->n_spmm_tiled++;
     if (!done) {
         RAILS_REQUIRE(A->variant != 2 && A->variant != 6, "rails_spmm: LDS-staged kernel requested but not applicable to this operator/shape");
