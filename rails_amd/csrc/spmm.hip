@@ -233,13 +233,13 @@ __global__ __launch_bounds__(256) void k_spmm_rowgather_cc(int64_t m, const int6
 // 24-bit multiply-add for the byte offset, one 16-byte load with a scalar base, two multiply-adds.  Kernel 1b spends ~37 vector
 // instructions per nonzero on 64-bit addresses, the ghost-row select and the masks of its tail and ran at the instruction rate
 // (rocprofv3 --pmc: 2000 VALU instructions per wave of 16 rows, TA and L2 far from busy): 0.40 ms at 16 columns, 18 % of the HBM rate.
-template <int RPG, bool GHOST>
+template <int RPG, bool GHOST, int LPR = 8>
 __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                      const double *__restrict__ val, const double *__restrict__ X, uint32_t ldx8,
                                                      const double *__restrict__ Xg, uint32_t ldg8, double *__restrict__ Y, int ldy, int nc,
                                                      int64_t blocks_per_xcd, int y_vec)
 {
-    constexpr int LPR = 8, GROUPS = 256 / LPR, ROWS = GROUPS * RPG, CAP = 2048;
+    constexpr int GROUPS = 256 / LPR, ROWS = GROUPS * RPG, CAP = 2048; // LPR lanes own a row: 16 columns with 8, 32 with 16
     __shared__ double s_val[CAP];
     __shared__ int32_t s_col[CAP];
     const int g = threadIdx.x / LPR;
@@ -340,13 +340,13 @@ int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, con
     const int64_t grid = bpx * 8 * nchunks;
     RAILS_REQUIRE(grid <= 0x7fffffffLL, "rails_spmm: grid too large");
     const int lds_cap = 2048; // nonzeros of one block staged in LDS (24 KiB); longer runs read (col, val) from global memory
-    if (LPR == 8 && nchunks == 1) {
+    if ((LPR == 8 || LPR == 16) && nchunks == 1) {
         // every X row at X + c * ldx (no ghost rows; a rectangular operator's extra rows follow X in the same panel) within 32-bit byte offsets
         static const int narrow_fast = spmm_env("RAILS_SPMM_NARROW_FAST", 1);
         const bool flat = (A->n_ghost == 0 && !A->rect) || (Xg == X + (int64_t)A->m * ldx && ldg == ldx);
         const bool small = A->ncols_ext < (1 << 24) && (int64_t)ldx * 8 < (1 << 24) && (int64_t)ldg * 8 < (1 << 24);
         if (narrow_fast && small && flat && (uint64_t)A->ncols_ext * (uint64_t)ldx * 8u < 0xffffff00ull) {
-            RAILS_LAUNCH((k_spmm_narrow<RPG, false>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, X, 0u, Y,
+            RAILS_LAUNCH((k_spmm_narrow<RPG, false, (LPR == 16 ? 16 : 8)>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, X, 0u, Y,
                          ldy, nc, bpx, y_vec ? 1 : 0);
             if (kernel) *kernel = "k_spmm_narrow";
             return RAILS_OK;
@@ -354,7 +354,7 @@ int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, con
         // row-partitioned runs: columns >= m are ghost rows in the halo buffer (16-byte aligned rows there too)
         if (narrow_fast && small && !flat && !A->rect && (uint64_t)A->m * (uint64_t)ldx * 8u < 0xffffff00ull &&
             (uint64_t)(A->ncols_ext - A->m) * (uint64_t)ldg * 8u < 0xffffff00ull ) {
-            RAILS_LAUNCH((k_spmm_narrow<RPG, true>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, Xg,
+            RAILS_LAUNCH((k_spmm_narrow<RPG, true, (LPR == 16 ? 16 : 8)>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, Xg,
                          (uint32_t)ldg * 8u, Y, ldy, nc, bpx, y_vec ? 1 : 0);
             if (kernel) *kernel = "k_spmm_narrow";
             return RAILS_OK;
@@ -721,15 +721,15 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     if (!done) {
         RAILS_REQUIRE(A->variant != 2 && A->variant != 6, "rails_spmm: LDS-staged kernel requested but not applicable to this operator/shape");
         int cc = vec2 ? rowgather_chunk(A, nc) : 0;
-        // narrow panels (the in-loop A*W at Expand size <= 16): the same kernel with one chunk -- (col, val) of a 64-row block staged
-        // in LDS instead of per-lane vector-memory loads: 0.38 vs 0.45 ms at 16 columns (banded), 0.37 vs 0.42 (stencil); at 32
-        // columns the two forms tie, so that stays with the plain kernel (RAILS_SPMM_NARROW_CC=0 disables, =2 also takes 32)
+        // narrow panels (the in-loop A*W at Expand size <= 32): one chunk, (col, val) of a 64-row block staged in LDS instead of
+        // per-lane vector-memory loads -- kernel 1c where every X row is within 32-bit byte offsets (0.24 vs 0.45 ms at 16 columns,
+        // 0.44 vs 0.71 ms at 32, banded pattern), kernel 1b otherwise (RAILS_SPMM_NARROW_CC=0 disables both)
         static const int narrow_env = spmm_env("RAILS_SPMM_NARROW_CC", 1);
         // (the gathers need 16-byte aligned X rows; a Y window on an odd column -- A*W written behind an odd number of basis columns --
         // only changes the form of the stores)
         const bool x_vec2 = (xc0 & 1) == 0 && (X->ld % 2 == 0) && (ldg % 2 == 0);
         const bool y_vec2 = (yc0 & 1) == 0 && (Y->ld % 2 == 0);
-        if (cc == 0 && x_vec2 && narrow_env && A->variant != 3 && nc > 8 && nc <= (narrow_env == 2 ? 32 : 16) && A->max_row_nnz <= 64) cc = nc <= 16 ? 16 : -32;
+        if (cc == 0 && x_vec2 && narrow_env && A->variant != 3 && nc > 8 && nc <= 32 && A->max_row_nnz <= 64) cc = nc <= 16 ? 16 : -32;
         // X rows that are only 8-byte aligned (a window on an odd column: A*W of the direct back end, W a view of V): kernel 1c loads its
         // two doubles with one 16-byte instruction all the same (global memory asks for dword alignment); kernel 1b does not take them
         bool narrow_only = false;
@@ -744,7 +744,7 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         if (launched)
             ;
         else if (cc == -32)
-            RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, y_vec2)));
+            RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, y_vec2, &cc_kernel)));
         else if (cc == 32)
             RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
         else if (cc == 64)

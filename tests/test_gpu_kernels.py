@@ -572,9 +572,9 @@ def test_small_cholesky_inverse_on_the_device(ctx, w):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nc,xoff,yoff", [(16, 0, 0), (16, 2, 3), (12, 0, 0), (11, 0, 2), (9, 4, 1), (16, 1, 0), (13, 3, 2)])
+@pytest.mark.parametrize("nc,xoff,yoff", [(16, 0, 0), (16, 2, 3), (12, 0, 0), (11, 0, 2), (9, 4, 1), (16, 1, 0), (13, 3, 2), (32, 0, 0), (24, 2, 1), (31, 0, 0)])
 def test_narrow_product_is_bitwise_the_rowgather_result(ctx, oracle, nc, xoff, yoff):
-    """The in-loop product A * W at Expand size <= 16 (`A_ * W`, src/LyapunovSolver.hpp:146; k_spmm_narrow, spmm.hip kernel 1c): rows of
+    """The in-loop product A * W at Expand size <= 32 (`A_ * W`, src/LyapunovSolver.hpp:146; k_spmm_narrow, spmm.hip kernel 1c): rows of
     0 to 60 entries (full groups of eight, tails of one to seven, blocks whose entries do not fit the LDS buffer), odd last columns,
     odd output offsets and odd input offsets (rows that are only 8-byte aligned: W as a view of V in the direct back end), against the whole-width row-gather kernel bit for bit and against the oracle's CSR product."""
     import rails_amd
