@@ -219,9 +219,9 @@ int rails_panel_gemm(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0
 
 /* The platform's BLAS (rocBLAS, resolved with dlopen) for the one plain wide GEMM of the library: rails_panel_gemm_wide with
  * k, r >= 64 (the basis rotation of the coordinate-space back end, compute-bound: 44 instead of 30 TFLOP/s).  Creating its handle takes
- * ~0.3 s (once per process, for the calling context's device): call this when the process sets up; the coordinate-space back end
- * calls it by itself at the second restart a process sees.  Until then -- rails_ctx_library_gemm_ready -- or without the library
- * (or with RAILS_WIDE_GEMM=own) the hand-written kernel does the work. */
+ * ~0.3 s in a warm process, seconds in a cold one (once per process, for the calling context's device): an application that is going
+ * to solve many systems calls this when it sets up; nothing in the library does by itself.  Until then --
+ * rails_ctx_library_gemm_ready -- or without the library (or with RAILS_WIDE_GEMM=own) the hand-written kernel does the work. */
 int rails_ctx_enable_library_gemm(rails_ctx *ctx);
 int rails_ctx_library_gemm_ready(const rails_ctx *ctx);
 

@@ -818,8 +818,9 @@ constexpr int ROCBLAS_OP_N = 111, ROCBLAS_OP_T = 112;
 
 // One handle per process (for the device of the first context that asks).  rocblas_create_handle takes 0.3 s and is NOT done behind the
 // caller's back on another thread (tried: a native program that starts using the GPU at once crashed now and then while rocBLAS was
-// loading its code objects): whoever wants the library path asks for it at a convenient moment -- bench.py when it sets up, the
-// coordinate-space back end at the second restart a process sees (by then the process is a long-running one).
+// loading its code objects): whoever wants the library path asks for it at a convenient moment -- bench.py when it sets up.  The
+// coordinate-space back end used to ask at the second restart a process saw; in a cold process that was a stall of seconds (the
+// library and its kernels come from disk) for 2 ms saved per restart, so it no longer does.
 namespace {
 struct LibraryGemm {
     std::atomic<int> state{0}; // 0 not asked for, 2 ready, 3 not available

@@ -36,11 +36,13 @@ struct Acc<2> {
     __device__ __forceinline__ void zero() { v = (double2_t){0.0, 0.0}; }
     __device__ __forceinline__ void fma(double a, const double *x)
     {
-        double2_t t = *reinterpret_cast<const double2_t *>(x);
+        // (16-byte accesses that may be only 8-byte aligned -- windows on odd columns, odd panel strides: global memory asks for dword
+        // alignment, and the instructions are the same ones)
+        double2_t t = *reinterpret_cast<const double2_a8_t *>(x);
         v.x = __builtin_fma(a, t.x, v.x);
         v.y = __builtin_fma(a, t.y, v.y);
     }
-    __device__ __forceinline__ void store(double *y) { *reinterpret_cast<double2_t *>(y) = v; }
+    __device__ __forceinline__ void store(double *y) { *reinterpret_cast<double2_a8_t *>(y) = v; }
 };
 
 // One group of LPR lanes per row, RPG consecutive rows per group.
@@ -749,7 +751,7 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
             RAILS_TRY((launch_rg_cc<16>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
         else if (cc == 64)
             RAILS_TRY((launch_rg_cc<32>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
-        else if (vec2)
+        else if (vec2 || nc >= 2) // (two columns per lane whatever the alignment of the windows: see Acc<2>)
             RAILS_TRY((dispatch_rg<2>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));
         else
             RAILS_TRY((dispatch_rg<1>(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc)));

@@ -392,10 +392,9 @@ public:
     void compress()
     {
         if (!resolve_pending()) return;
-        // the rotation below is a plain wide GEMM: from the second restart a process sees it goes through the platform's BLAS (0.3 s to
-        // set up, once: a process that restarts twice is going to be around for a while; bench.py asks for it when it sets up)
-        static std::atomic<int> restarts_seen{0};
-        if (++restarts_seen == 2) hip_ok(rails_ctx_enable_library_gemm(ctx), "rails_ctx_enable_library_gemm");
+        // (the rotation below is a plain wide GEMM: it goes through the platform's BLAS where the application has asked for that --
+        // rails_ctx_enable_library_gemm, as bench.py does when it sets up.  Not by itself: loading the library and its kernels takes
+        // 0.3 s in a warm process and several seconds in a cold one, against 2 ms saved per restart.)
         std::vector<std::shared_ptr<CoefStore>> stores;
         std::vector<std::weak_ptr<CoefStore>> still;
         int ncols = 0;

@@ -160,8 +160,8 @@ def test_solver_full_size_both_back_ends(ctx, c3):
         assert np.abs(T - T.T).max() <= 1e-12 * np.abs(T).max()
         Vd = MV(ctx, data=V)
         # the reference does not re-orthogonalise after restarts (:270) either.  Measured: 5e-15 on the coordinate-space back end; on the
-        # direct one 0.9e-10 .. 1.2e-10 depending on which kernel rotated the basis at the restarts (the library GEMM once a process has
-        # seen two restarts, the hand-written one before: scripts/orth_probe.py) -- the CholQR of the nearly dependent A*V blocks sets it
+        # direct one 0.9e-10 .. 1.2e-10 depending on which kernel rotated the basis at the restarts (the library GEMM where a process has
+        # asked for it, the hand-written one otherwise: scripts/orth_probe.py) -- the CholQR of the nearly dependent A*V blocks sets it
         assert np.abs(Vd.dot(Vd) - np.eye(k)).max() <= (1e-12 if subspace else 5e-10)
         assert s.relative_residual() < PARAMS["Tolerance"]
         # the reference's own acceptance, re-evaluated independently: ||R||_2 < tol * ||B||_2^2.  The solver's value is a
