@@ -230,7 +230,7 @@ int rails_ctx_library_gemm_ready(const rails_ctx *ctx);
  * `doubles_per_slot` doubles on the device with a pinned mirror; rails_gram_deferred leaves X'Y (a x b, leading dimension a, summed
  * over the ranks) in a slot and sends it on its way to the mirror; rails_panel_gemm_deferred takes the coefficient matrix of
  * Y = beta Y + alpha X C from a slot (rows [0, k) of its r columns, leading dimension ld); rails_chol_inverse_deferred turns the w x w
- * Gram matrix G of a slot (w <= 32) into D^-1 R^-1 (D = sqrt(diag G), R'R = D^-1 G D^-1) in another slot.  None of them synchronises;
+ * Gram matrix G of a slot (w <= 48) into D^-1 R^-1 (D = sqrt(diag G), R'R = D^-1 G D^-1) in another slot.  None of them synchronises;
  * rails_deferred_fetch copies from the mirror and is valid after a rails_ctx_sync that follows the call which filled the slot. */
 int rails_deferred_reserve(rails_ctx *ctx, int nslots, int64_t doubles_per_slot);
 int rails_gram_deferred(rails_ctx *ctx, const rails_panel *X, int xc0, int a, const rails_panel *Y, int yc0, int b, int slot);

@@ -415,7 +415,7 @@ __global__ void k_compact_cols(const double *__restrict__ src, int ld, int k, in
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) dst[q] = src[(q / k) * ld + (q % k)];
 }
 
-// G (w x w, symmetric positive definite, w <= 32) -> M = D^-1 R^-1 with D = sqrt(diag G), R'R = D^-1 G D^-1 (upper triangular):
+// G (w x w, symmetric positive definite, w <= 48) -> M = D^-1 R^-1 with D = sqrt(diag G), R'R = D^-1 G D^-1 (upper triangular):
 // X M has orthonormal columns when X'X = G.  One wave, lane j = column j: a right-looking Cholesky (row i of R, then the rank-one update
 // of the columns behind it: w steps of at most w dependent LDS round trips each) and one back substitution per lane for R^-1 -- about
 // ten microseconds at w = 17, where one thread working through the ~w^3 / 2 dependent operations took 110 (two of these sit on the
@@ -423,40 +423,41 @@ __global__ void k_compact_cols(const double *__restrict__ src, int ld, int k, in
 // of G and decides).
 __global__ __launch_bounds__(64) void k_small_chol(const double *__restrict__ G, int w, double *__restrict__ M)
 {
-    __shared__ double S[32 * 33], Ri[32 * 33], d[32];
+    constexpr int LD = 49; // up to 48 columns (Expand size 32 + the prefetched random vector: 33), rows of S a bank apart
+    __shared__ double S[48 * LD], Ri[48 * LD], d[48];
     const int t = threadIdx.x;
     const bool mine = t < w;
-    for (int q = t; q < w * w; q += 64) S[(q / w) * 33 + (q % w)] = G[q]; // S[col][row]
+    for (int q = t; q < w * w; q += 64) S[(q / w) * LD + (q % w)] = G[q]; // S[col][row]
     __syncthreads();
-    if (mine) d[t] = sqrt(S[t * 33 + t]);
+    if (mine) d[t] = sqrt(S[t * LD + t]);
     __syncthreads();
-    for (int q = t; q < w * w; q += 64) S[(q / w) * 33 + (q % w)] /= d[q % w] * d[q / w];
+    for (int q = t; q < w * w; q += 64) S[(q / w) * LD + (q % w)] /= d[q % w] * d[q / w];
     __syncthreads();
     // R[i][j] (i <= j) ends up at S[j][i]
     for (int i = 0; i < w; ++i) {
-        const double piv = sqrt(S[i * 33 + i]);
+        const double piv = sqrt(S[i * LD + i]);
         double rij = 0.0;
-        if (mine && t >= i) rij = (t == i) ? piv : S[t * 33 + i] / piv;
+        if (mine && t >= i) rij = (t == i) ? piv : S[t * LD + i] / piv;
         __syncthreads();
-        if (mine && t >= i) S[t * 33 + i] = rij;
+        if (mine && t >= i) S[t * LD + i] = rij;
         __syncthreads();
         if (mine && t > i)
-            for (int l = i + 1; l <= t; ++l) S[t * 33 + l] -= S[l * 33 + i] * rij;
+            for (int l = i + 1; l <= t; ++l) S[t * LD + l] -= S[l * LD + i] * rij;
         __syncthreads();
     }
     // column t of R^-1 by back substitution (every lane its own column: no exchange)
     if (mine) {
-        for (int l = 0; l < w; ++l) Ri[t * 33 + l] = 0.0;
+        for (int l = 0; l < w; ++l) Ri[t * LD + l] = 0.0;
         for (int i = t; i >= 0; --i) {
             double s = (i == t) ? 1.0 : 0.0;
-            for (int l = i + 1; l <= t; ++l) s -= S[l * 33 + i] * Ri[t * 33 + l];
-            Ri[t * 33 + i] = s / S[i * 33 + i];
+            for (int l = i + 1; l <= t; ++l) s -= S[l * LD + i] * Ri[t * LD + l];
+            Ri[t * LD + i] = s / S[i * LD + i];
         }
     }
     __syncthreads();
     for (int q = t; q < w * w; q += 64) {
         const int j = q / w, i = q % w;
-        M[q] = i <= j ? Ri[j * 33 + i] / d[i] : 0.0;
+        M[q] = i <= j ? Ri[j * LD + i] / d[i] : 0.0;
     }
 }
 
@@ -736,7 +737,7 @@ extern "C" int rails_update_gram_deferred(rails_ctx *c, double alpha, const rail
 extern "C" int rails_chol_inverse_deferred(rails_ctx *c, int slot_in, int w, int slot_out)
 {
     if (c) hipSetDevice(c->device);
-    RAILS_REQUIRE(c && w >= 1 && w <= 32 && slot_in != slot_out, "rails_chol_inverse_deferred: bad argument (w = %d)", w);
+    RAILS_REQUIRE(c && w >= 1 && w <= 48 && slot_in != slot_out, "rails_chol_inverse_deferred: bad argument (w = %d)", w);
     RAILS_SLOT_CHECK(slot_in, (size_t)w * w, "rails_chol_inverse_deferred");
     RAILS_SLOT_CHECK(slot_out, (size_t)w * w, "rails_chol_inverse_deferred");
     RAILS_LAUNCH(k_small_chol, dim3(1), dim3(64), 0, c->stream, c->defer_dev + (size_t)slot_in * c->defer_slot, w, c->defer_dev + (size_t)slot_out * c->defer_slot);

@@ -254,7 +254,7 @@ public:
                 }
                 if (trace) std::cerr << "absorb: dim " << dim << " w " << w << " first round: smallest survival " << worst << ", second round on " << w2 << " columns" << std::endl;
                 // (the overlapped form queues the update of this round itself: fused with the second projection, one pass over P)
-                if (overlap && w <= 32 && worst >= overlap_min_survival && start_overlapped(w, w2, coef, CG, G0)) return true;
+                if (overlap && w <= 48 && worst >= overlap_min_survival && start_overlapped(w, w2, coef, CG, G0)) return true;
                 if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, dim, CG.data(), dw, wr, 1.0, pp, dim), "rails_panel_gemm")) return fail();
                 if (w2 == 0) break;
                 n_second_round++;
@@ -507,7 +507,7 @@ public:
         if (info != 0) return false;
         for (int a = 0; a < w; ++a)
             if (!(R1[a + (size_t)a * w] > 1e-2)) return false; // an ill-conditioned block takes the careful way (re-projection)
-        if (!hip_ok(rails_deferred_reserve(ctx, N_SLOTS, (int64_t)(P.capacity() + 64) * 32), "rails_deferred_reserve")) return false;
+        if (!hip_ok(rails_deferred_reserve(ctx, N_SLOTS, (int64_t)(P.capacity() + 64) * (w <= 32 ? 32 : 48)), "rails_deferred_reserve")) return false;
         // the device's part: the first update, the second round on the leading w2 columns, Gram matrix of the block, its Cholesky
         // factor inverted, Q1 = X M1, the same once more (CholQR2)
         rails_panel *pp = P.panel();

@@ -541,7 +541,7 @@ def test_update_and_second_projection_in_one_pass(ctx, m, k, r, r2, xoff):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w", [1, 2, 16, 17, 31, 32])
+@pytest.mark.parametrize("w", [1, 2, 16, 17, 31, 32, 33, 48])
 def test_small_cholesky_inverse_on_the_device(ctx, w):
     """rails_chol_inverse_deferred (k_small_chol: one wave, a column per lane): M = D^-1 R^-1 with R'R = D^-1 G D^-1, so that M' G M = I,
     for every block width the back end uses, on a Gram matrix with a wide range of column norms."""
@@ -555,7 +555,7 @@ def test_small_cholesky_inverse_on_the_device(ctx, w):
     m = 20000
     Xh = g.uniform(-1, 1, (m, w)) * np.logspace(0, 5, w)[None, :]
     X = rails_amd.HipMultiVectorWrapper(ctx, data=Xh)
-    chk(lib.rails_deferred_reserve(ctx.h, 3, 64 * 32), "rails_deferred_reserve")
+    chk(lib.rails_deferred_reserve(ctx.h, 3, 64 * 48), "rails_deferred_reserve")
     chk(lib.rails_gram_deferred(ctx.h, X.panel.h, 0, w, X.panel.h, 0, w, 0), "gram")
     chk(lib.rails_chol_inverse_deferred(ctx.h, 0, w, 1), "chol")
     ctx.sync()
