@@ -100,9 +100,9 @@ extern "C" int rails_ctx_stats(rails_ctx *c, char *buf, int cap)
 {
     RAILS_REQUIRE(c && buf && cap > 0, "rails_ctx_stats: bad argument");
     int n = snprintf(buf, (size_t)cap,
-                     "{\"orth_block\": %ld, \"orth_columnwise\": %ld, \"spmm_tiled\": %ld, \"spmm_sweep\": %ld, \"spmm_rowgather\": %ld, \"spmm_callback\": %ld, \"device_allocations\": %ld, \"allreduce\": %ld, "
+                     "{\"orth_block\": %ld, \"orth_columnwise\": %ld, \"spmm_tiled\": %ld, \"spmm_planes\": %ld, \"spmm_sweep\": %ld, \"spmm_rowgather\": %ld, \"spmm_callback\": %ld, \"device_allocations\": %ld, \"allreduce\": %ld, "
                      "\"lanczos\": %ld, \"lanczos_start\": %ld, \"orth_repair\": %ld, \"update_gram_fused\": %ld, \"gpu_busy_ms\": %.3f}",
-                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_sweep, c->n_spmm_rowgather, c->n_spmm_callback, c->n_dev_alloc, c->n_allreduce, c->n_lanczos, c->n_lanczos_start, c->n_orth_repair, c->n_update_gram_fused, c->gpu_busy_ms);
+                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_planes, c->n_spmm_sweep, c->n_spmm_rowgather, c->n_spmm_callback, c->n_dev_alloc, c->n_allreduce, c->n_lanczos, c->n_lanczos_start, c->n_orth_repair, c->n_update_gram_fused, c->gpu_busy_ms);
     RAILS_REQUIRE(n > 0 && n < cap, "rails_ctx_stats: buffer too small");
     return RAILS_OK;
 }

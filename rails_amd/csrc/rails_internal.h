@@ -88,7 +88,7 @@ struct rails_ctx {
     double gpu_busy_ms = 0.0;
     // counters (rails_ctx_stats)
     void *lz = nullptr; // rails_lanczos_state (lanczos.hip), released by rails_lanczos_release
-    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_sweep = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_dev_alloc = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0, n_update_gram_fused = 0;
+    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_planes = 0, n_spmm_sweep = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_dev_alloc = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0, n_update_gram_fused = 0;
 };
 
 // the busy meter (see rails_ctx): RAILS_LAUNCH brackets a launch, rails_stream_sync reads what has been bracketed since the last one
@@ -129,11 +129,13 @@ struct rails_panel {
     int ld = 0;
 };
 
+struct rails_planes_plan; // spmm_planes.hip: coefficient records of a structured-grid stencil
 struct rails_sweep_cache; // spmm_sweep.hip: device copies of the sweep kernel's schedules, one per column-chunk count
 
 struct rails_csr {
     rails_ctx *ctx = nullptr;
     rails_sweep_cache *sweep = nullptr;
+    rails_planes_plan *planes = nullptr;
     int64_t m = 0, ncols_ext = 0, nnz = 0;
     bool rect = false; // rails_csr_create_rect: n_rows x n_cols with n_cols != n_rows, all columns local (X has ncols_ext rows, Y has m)
     int64_t *rowptr = nullptr;
@@ -238,6 +240,10 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
                      bool force, bool *done);
 int rails_sweep_prepare(rails_ctx *c, rails_csr *A, int nc, bool *fits); // the schedule for nc columns, now
 void rails_sweep_release(rails_csr *A);
+// spmm_planes.hip: the plane-sweep kernel for structured-grid stencils; *done tells whether it computed the product
+int rails_spmm_planes(rails_ctx *c, rails_csr *A, const double *X, int ldx, double *Y, int ldy, int nc, bool aligned, bool build, bool *done);
+void rails_planes_release(rails_csr *A);
+bool rails_detect_grid(const rails_csr *A, int64_t *nx, int64_t *ny, int64_t *nz); // spmm.hip
 // dense.hip: partial Gram into device memory (no host copy / all-reduce): C_dev (a x b col-major, ldc = a)
 int rails_gram_dev(rails_ctx *ctx, const double *X, int ldx, const double *Y, int ldy, int64_t m, int a, int b,
                    double *C_dev);

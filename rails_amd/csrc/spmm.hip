@@ -505,6 +505,7 @@ extern "C" int rails_csr_destroy(rails_csr *A)
     hipStreamSynchronize(A->ctx->stream);
     if (A->AT) rails_csr_destroy(A->AT);
     rails_sweep_release(A);
+    rails_planes_release(A);
     if (A->rowptr) hipFree(A->rowptr);
     if (A->col) hipFree(A->col);
     if (A->val) hipFree(A->val);
@@ -542,7 +543,7 @@ extern "C" int rails_csr_create_rect(rails_ctx *c, int64_t n_rows, int64_t n_col
 
 extern "C" int rails_csr_set_variant(rails_csr *A, int variant)
 {
-    RAILS_REQUIRE(A && variant >= 0 && variant <= 8, "rails_csr_set_variant: bad argument");
+    RAILS_REQUIRE(A && variant >= 0 && variant <= 9, "rails_csr_set_variant: bad argument");
     if (A->rect) return RAILS_OK; // rectangular operators stay on the plain row-gather kernel
     A->variant = variant;
     return RAILS_OK;
@@ -712,6 +713,17 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         const bool al = ((xc0 | yc0) & 1) == 0 && X->ld % 2 == 0 && Y->ld % 2 == 0 && ldg % 2 == 0;
         RAILS_TRY(rails_spmm_sweep(c, A, Xp, X->ld, Xg, ldg, Yp, Y->ld, nc, al, A->variant == 7, &done));
         if (done) return RAILS_OK;
+    }
+    // structured-grid stencils (complete 7- / 27-point patterns): the plane-sweep kernel (spmm_planes.hip) at every even width
+    // -- its plan is one pass over the matrix on the device (a product's worth of time), made by the first product that asks
+    if (A->variant == 9 || (A->variant == 0 && nc >= 2 && A->n_ghost == 0 && !A->rect && spmm_env("RAILS_SPMM_PLANES", 1) && rails_csr_is_grid(A))) {
+        const bool al = ((xc0 | yc0) & 1) == 0 && X->ld % 2 == 0 && Y->ld % 2 == 0;
+        RAILS_TRY(rails_spmm_planes(c, A, Xp, X->ld, Yp, Y->ld, nc, al, true, &done));
+        if (done) {
+            c->n_spmm_planes++;
+            return RAILS_OK;
+        }
+        RAILS_REQUIRE(A->variant != 9, "rails_spmm: plane-sweep kernel requested but not applicable to this operator/shape");
     }
     // at Expand size <= 16 the lean row kernel (1c) beats the LDS-staged box kernel on the stencils too (27-point: 0.206 against 0.256 ms,
     // 7-point: 0.097 against 0.130): in automatic mode the box kernel is for wider panels
@@ -1312,6 +1324,8 @@ int upload(T **dst, const std::vector<T> &src)
 }
 
 } // namespace
+
+bool rails_detect_grid(const rails_csr *A, int64_t *nx, int64_t *ny, int64_t *nz) { return detect_grid(A, nx, ny, nz); }
 
 static bool rails_csr_is_grid(rails_csr *A)
 {

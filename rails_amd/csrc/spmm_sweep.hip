@@ -88,6 +88,9 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_DPPSFX "_dpp"
 #define RAILS_SW_QP(T) "quad_perm:[" #T "," #T "," #T "," #T "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #include "spmm_sweep_kernel.inc"
+// ---- experiment builds (timings only: their results are wrong by construction).  Compiled only with -DRAILS_SWEEP_EXPERIMENTS
+// (`make EXPERIMENTS=1`, what scripts/gpu_sweep*.sh use); the shipped library has none of them and refuses RAILS_SWEEP_ABLATE / RAILS_SWEEP_LAYOUT.
+#ifdef RAILS_SWEEP_EXPERIMENTS
 // the full kernel with the run-time experiment switches (RAILS_SWEEP_ABLATE & 7: no LDS-DMA / no trips / no barriers)
 #define RAILS_SW_NAME k_spmm_sweep_switches
 #define RAILS_SW_ABLATE a.ablate
@@ -195,6 +198,7 @@ constexpr int SWEEP_ACC0 = 24;
 #define RAILS_SW_DPPSFX ""
 #define RAILS_SW_QP(T) ""
 #include "spmm_sweep_kernel.inc"
+#endif // RAILS_SWEEP_EXPERIMENTS
 
 struct DevPlan {
     rails_sweep_plan host; // kept for its small arrays and statistics (the big arrays are released after the upload)
@@ -351,9 +355,15 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
     a.n_chunks = n_chunks;
     a.phases = 32 / n_chunks;
     static const int ablate = getenv("RAILS_SWEEP_ABLATE") ? atoi(getenv("RAILS_SWEEP_ABLATE")) : 0;
-    a.ablate = ablate;
     static const int layout = getenv("RAILS_SWEEP_LAYOUT") ? atoi(getenv("RAILS_SWEEP_LAYOUT")) : 0;
+#ifndef RAILS_SWEEP_EXPERIMENTS
+    // the experiment switches select kernels whose results are wrong by construction: a library built without them refuses the product
+    // instead of returning one (a leftover export of a profiling script must not corrupt a solve)
+    RAILS_REQUIRE(!ablate && !layout, "rails_spmm: RAILS_SWEEP_ABLATE / RAILS_SWEEP_LAYOUT are set, but this library has no experiment builds of the sweep kernel (make EXPERIMENTS=1)");
+#endif
+    a.ablate = ablate;
     a.layout = layout;
+    const char *launched = d->host.p.entry_trips == 2 ? "k_spmm_sweep_h2" : "k_spmm_sweep";
 #define RAILS_SWEEP_LAUNCH(K)                                                                                                                     \
     RAILS_LAUNCH((K<SWEEP_W, SWEEP_G>), dim3(256), dim3(SWEEP_W * 64), 0, c->stream, a, d->part_row0, d->sweep0, d->nsteps, d->hdr_off, \
                        d->batch_off, d->codes, d->vals, d->offs, X, Xg, Y)
@@ -361,23 +371,28 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
         RAILS_REQUIRE(!ablate, "rails_spmm: the experiment builds of the sweep kernel take schedules with entries of four trips (RAILS_SWEEP_ENTRY_TRIPS)");
         RAILS_SWEEP_LAUNCH(k_spmm_sweep_h2);
     } else
+#ifdef RAILS_SWEEP_EXPERIMENTS
     switch ((ablate >> 4) & 15) {
-    case 1: RAILS_SWEEP_LAUNCH(k_spmm_sweep_noread); break;
-    case 2: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nofma); break;
-    case 3: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nowait); break;
-    case 4: RAILS_SWEEP_LAUNCH(k_spmm_sweep_noidx); break;
-    case 5: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nodpp); break;
-    case 6: RAILS_SWEEP_LAUNCH(k_spmm_sweep_bare); break;
-    case 7: RAILS_SWEEP_LAUNCH(k_spmm_sweep_halves); break;
+    case 1: RAILS_SWEEP_LAUNCH(k_spmm_sweep_noread); launched = "k_spmm_sweep_noread (experiment: wrong result)"; break;
+    case 2: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nofma); launched = "k_spmm_sweep_nofma (experiment: wrong result)"; break;
+    case 3: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nowait); launched = "k_spmm_sweep_nowait (experiment: wrong result)"; break;
+    case 4: RAILS_SWEEP_LAUNCH(k_spmm_sweep_noidx); launched = "k_spmm_sweep_noidx (experiment: wrong result)"; break;
+    case 5: RAILS_SWEEP_LAUNCH(k_spmm_sweep_nodpp); launched = "k_spmm_sweep_nodpp (experiment: wrong result)"; break;
+    case 6: RAILS_SWEEP_LAUNCH(k_spmm_sweep_bare); launched = "k_spmm_sweep_bare (experiment: wrong result)"; break;
+    case 7: RAILS_SWEEP_LAUNCH(k_spmm_sweep_halves); launched = "k_spmm_sweep_halves (experiment)"; break;
     default:
-        if (ablate)
+        if (ablate) {
             RAILS_SWEEP_LAUNCH(k_spmm_sweep_switches);
-        else
+            launched = "k_spmm_sweep_switches (experiment: wrong result)";
+        } else
             RAILS_SWEEP_LAUNCH(k_spmm_sweep);
         break;
     }
+#else
+        RAILS_SWEEP_LAUNCH(k_spmm_sweep);
+#endif
     RAILS_HIP_CHECK(hipGetLastError());
-    A->last_kernel = d->host.p.entry_trips == 2 ? "k_spmm_sweep_h2" : "k_spmm_sweep";
+    A->last_kernel = launched;
     c->n_spmm_sweep++;
     *done = true;
     return RAILS_OK;

@@ -2,6 +2,8 @@
 # Sweep SpMM timing experiments, all on one box: every argument is a comma-separated list of environment settings for one run, e.g.
 #   bash scripts/gpu_sweep3.sh "" RAILS_SWEEP_LEVEL=0 RAILS_SWEEP_ABLATE=4,RAILS_SWEEP_LEVEL=0
 # (results of RAILS_SWEEP_ABLATE builds are wrong by construction: timings only)
+# the experiment builds of the sweep kernel are not in the shipped library: rebuild with them first (round 3)
+mkdir -p gpurun_out; make -s -C rails_amd/csrc EXPERIMENTS=1 -B -j16 > gpurun_out/build_experiments.log 2>&1 || exit 1
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp

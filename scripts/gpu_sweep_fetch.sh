@@ -1,6 +1,8 @@
 #!/bin/bash
 # Where the sweep kernel's HBM reads come from: FETCH_SIZE of the full kernel, without the LDS-DMA (stream + records only) and
 # without the trips (X rows + records only).  One --pmc pass each.
+# the experiment builds of the sweep kernel are not in the shipped library: rebuild with them first (round 3)
+mkdir -p gpurun_out; make -s -C rails_amd/csrc EXPERIMENTS=1 -B -j16 > gpurun_out/build_experiments.log 2>&1 || exit 1
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/sweep_fetch

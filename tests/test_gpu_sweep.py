@@ -192,8 +192,9 @@ def test_auto_choice_on_the_bench_matrix_and_its_transpose(ctx):
 
 
 def test_auto_leaves_structured_stencils_to_the_box_kernel(ctx):
-    """A 7-point Laplacian whose window fits the sweep's ring still goes to the LDS-staged box kernel in auto mode (few nonzeros per row
-    leave the sweep at its floor of one LDS-DMA latency per step: 0.82 against 0.65 ms at 50 x 50 x 400, 128 columns)"""
+    """A 7-point Laplacian whose window fits the sweep's ring goes to the stencil kernels in auto mode, not to the sweep (few nonzeros per row
+    leave the sweep at its floor of one LDS-DMA latency per step: 0.82 ms at 50 x 50 x 400, 128 columns, against 0.65 for the box kernel and
+    0.50 for the plane-sweep kernel, which takes complete stencils since round 3)"""
     import rails_amd
     from rails_amd import problems as P
 
@@ -203,7 +204,7 @@ def test_auto_leaves_structured_stencils_to_the_box_kernel(ctx):
     X = rails_amd.HipMultiVectorWrapper(ctx, m=m, n=128, capacity=128)
     X.random()
     Y = op.apply(X)
-    assert op.last_kernel() == "k_spmm_tiled_reg"
+    assert op.last_kernel() == "k_spmm_planes"
     op.set_variant(7)
     Ys = op.apply(X)
     assert op.last_kernel().startswith("k_spmm_sweep")
