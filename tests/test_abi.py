@@ -321,3 +321,16 @@ def test_wrappers_instantiate_the_reference_solver_template():
            "-I" + os.path.join(ROOT, "rails_amd", "include"), os.path.join(ROOT, "tests", "integration", "reference_solver_instantiation.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_shipped_library_has_no_experiment_builds_of_the_sweep_kernel():
+    """The sweep kernel's experiment instantiations (results wrong by construction: timings only) are compiled only with
+    `make EXPERIMENTS=1`; the shipped library holds the two product kernels and refuses RAILS_SWEEP_ABLATE / RAILS_SWEEP_LAYOUT."""
+    import rails_amd._lib as L
+
+    blob = open(L.LIB_PATH, "rb").read()
+    assert b"k_spmm_sweep_h2" in blob
+    for name in (b"k_spmm_sweep_noread", b"k_spmm_sweep_nofma", b"k_spmm_sweep_nowait", b"k_spmm_sweep_noidx", b"k_spmm_sweep_bare",
+                 b"k_spmm_sweep_nodpp", b"k_spmm_sweep_halves", b"k_spmm_sweep_switches"):
+        assert name not in blob, name
+    assert b"no experiment builds of the sweep kernel" in blob  # the refusal's message

@@ -250,3 +250,30 @@ def test_both_entry_sizes_are_bitwise_the_rowgather_result(ctx, monkeypatch, kin
     op.apply(X, Y)
     assert op.last_kernel() == "k_spmm_rowgather"
     assert np.array_equal(Ys, Y.to_host())
+
+
+def test_leftover_experiment_switch_is_refused_not_obeyed():
+    """RAILS_SWEEP_ABLATE selects experiment builds whose results are wrong by construction; the shipped library has none of them and a
+    product with the variable set fails loudly instead of returning a wrong panel (a leftover export of a profiling script)."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, rails_amd\n"
+        "from rails_amd import problems as P\n"
+        "ctx = rails_amd.Context(device=0, seed=1)\n"
+        "A = P.banded_random(131072, 27, 4096, seed=1)\n"
+        "op = rails_amd.HipOperatorWrapper(ctx, *A)\n"
+        "X = rails_amd.HipMultiVectorWrapper(ctx, m=131072, n=128, capacity=128)\n"
+        "X.random()\n"
+        "op.set_variant(7)\n"
+        "try:\n"
+        "    op.apply(X)\n"
+        "    print('COMPUTED', op.last_kernel())\n"
+        "except rails_amd.RailsError as e:\n"
+        "    print('REFUSED', e)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RAILS_SWEEP_ABLATE="16", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert "REFUSED" in out.stdout and "experiment builds" in out.stdout, out.stdout + out.stderr

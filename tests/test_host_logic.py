@@ -134,3 +134,18 @@ def test_row_ranges_and_halo_plan():
         rp, col, val = P.csr_rows(A, starts[r], starts[r + 1])
         glob = np.where(pl.col_local < pl.m_local, pl.col_local + starts[r], pl.ghost_globals[np.maximum(pl.col_local - pl.m_local, 0)])
         assert np.array_equal(glob, col.astype(np.int64))
+
+
+def test_compiled_reference_stays_in_the_build_container():
+    """The binary built from the reference's own sources (oracle/_ref, oracle/Makefile) is test infrastructure of the build container: it is
+    listed in .gpurunignore (it does not travel to the GPU box) and in .gitignore (it stays out of history), and where /root/reference does
+    not exist nothing may sit under oracle/_ref."""
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ignore = open(os.path.join(root, ".gpurunignore")).read().split()
+    assert "oracle/_ref/" in ignore
+    assert "oracle/_ref/" in open(os.path.join(root, ".gitignore")).read().split()
+    ref_dir = os.path.join(root, "oracle", "_ref")
+    if not os.path.isdir("/root/reference"):
+        assert not os.path.isdir(ref_dir) or not os.listdir(ref_dir), "a binary built from the reference has travelled: %s" % os.listdir(ref_dir)
