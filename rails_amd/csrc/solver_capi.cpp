@@ -196,6 +196,7 @@ static int solve_in_coordinates(rails_solver *s)
     solver.set_max_trips(s->max_trips);
     solver.use_mass_matrix(s->mass);
     if (s->trip_fn) solver.set_trip_callback([s](int trip) { s->trip_fn(s->trip_user, trip); });
+    solver.set_failure_check([basis]() { return basis->failed; }); // a latched failure of the basis ends the run at the next trip
     rails::SubspaceMultiVector Vc(basis, 1);
     if (s->have_V0) { // warm start: the caller's (orthonormal) V expressed in the basis (src/LyapunovSolver.hpp:116-123)
         Vc = rails::SubspaceMultiVector::Absorb(basis, s->V);
@@ -208,9 +209,9 @@ static int solve_in_coordinates(rails_solver *s)
     s->sub_hist = solver.residual_history();
     s->sub_profile = solver.profile();
     char buf[1024];
-    snprintf(buf, sizeof(buf), "{\"dim\": %d, \"absorb\": %ld, \"absorb_columns\": %ld, \"one_by_one\": %ld, \"dropped\": %ld, \"compress\": %ld, \"materialise\": %ld, \"prefetched_random\": %ld, \"second_rounds\": %ld, \"delicate_blocks\": %ld, \"reprojected_blocks\": %ld, \"overlapped_blocks\": %ld, \"seconds\": {\"materialise\": %.4f, \"absorb\": %.4f, \"compress_qr\": %.4f, \"compress_rotate\": %.4f, "
+    snprintf(buf, sizeof(buf), "{\"dim\": %d, \"absorb\": %ld, \"absorb_columns\": %ld, \"one_by_one\": %ld, \"dropped\": %ld, \"compress\": %ld, \"materialise\": %ld, \"prefetched_random\": %ld, \"second_rounds\": %ld, \"delicate_blocks\": %ld, \"reprojected_blocks\": %ld, \"overlapped_blocks\": %ld, \"replaced_columns\": %ld, \"seconds\": {\"materialise\": %.4f, \"absorb\": %.4f, \"compress_qr\": %.4f, \"compress_rotate\": %.4f, "
              "\"compress_coefficients\": %.4f}}",
-             basis->dim, basis->n_absorb, basis->n_absorb_cols, basis->n_single, basis->n_dropped, basis->n_compress, basis->n_materialise, basis->n_prefetched, basis->n_second_round, basis->n_delicate, basis->n_reprojected, basis->n_overlapped,
+             basis->dim, basis->n_absorb, basis->n_absorb_cols, basis->n_single, basis->n_dropped, basis->n_compress, basis->n_materialise, basis->n_prefetched, basis->n_second_round, basis->n_delicate, basis->n_reprojected, basis->n_overlapped, basis->n_replaced,
              basis->t_materialise, basis->t_absorb, basis->t_qr, basis->t_rotate, basis->t_recoef);
     s->sub_stats = buf;
     if (basis->failed) {

@@ -233,6 +233,8 @@ public:
     bool projected_lanczos() const { return projected_lanczos_; }
     bool mass_matrix_in_use() const { return mass_; }
     void set_trip_callback(std::function<void(int)> cb) { on_trip_ = cb; }
+    // asked once per trip: true ends the run with the code of "stopped without converging" (a back end whose device work has failed)
+    void set_failure_check(std::function<bool()> f) { broken_ = f; }
     int trips() const { return trips_; }
     std::vector<double> const &residual_history() const { return estimates_; }
     std::map<std::string, double> const &profile() const { return sections_; }
@@ -426,6 +428,10 @@ private:
                         converged_once_ = true;
                     else
                         return finish(converged, estimate);
+                }
+                if (s_.broken_ && s_.broken_()) { // extension: the back end has latched a failure -- no point in running on (the caller reports it)
+                    s_.notify();
+                    return -1;
                 }
                 if (s_.trip_budget_ > 0 && s_.trips_ >= s_.trip_budget_) { // extension: bounded run
                     s_.notify();
@@ -653,6 +659,7 @@ protected:
     int trips_ = 0;
     std::vector<double> estimates_;
     std::function<void(int)> on_trip_;
+    std::function<bool()> broken_;
     std::map<std::string, double> sections_;
     bool projected_lanczos_ = false;
 };

@@ -475,3 +475,61 @@ def test_subspace_backend_overlap_on_and_off(oracle, monkeypatch):
     out = oracle.solve(A, B, oracle.params({**params, "rng_mode": 1, "seed": 9}))
     Xo = out["V"] @ out["T"] @ out["V"].T
     assert np.linalg.norm(X1 - Xo) <= 10 * params["Tolerance"] * np.linalg.norm(Xo)
+
+
+def test_subspace_backend_rank_deficient_expansion_blocks(ctx):
+    """A = -I + 0.3 x y': every A*W block is -W (already in the basis) plus multiples of ONE new direction -- nearly dependent columns whose
+    projections are parallel.  Such blocks fail the conditions of the overlapped orthogonalisation (predicted Cholesky factor) and take the
+    synchronous careful path; the basis stays orthonormal, nothing is absorbed twice, and the solution satisfies the equation."""
+    from rails_amd import problems as P
+
+    n = 256
+    g = np.random.default_rng(12)
+    x, y = g.standard_normal(n), g.standard_normal(n)
+    x /= np.linalg.norm(x)
+    y /= np.linalg.norm(y)
+    Ad = -np.eye(n) + 0.3 * np.outer(x, y)
+    B = P.rhs(n, 4, seed=3)
+    params = {"Restart size": 40, "Reduced size": 20, "Expand size": 4, "Lanczos iterations": 8, "Tolerance": 1e-9}
+    code, V, T, s = _solve(ctx, P.dense_to_csr(Ad), B, params, seed=4, options={"subspace": 1})
+    assert code == 0
+    st = s.backend_stats()
+    # span[B, x] has 4 + 1 directions (+ the random start vectors of the Lanczos runs): most of every A*W block is dropped, and the
+    # expansion vectors that lie in span(V) already are replaced by random directions (the reference normalises rounding noise there)
+    assert st["dropped"] > 0 and st["replaced_columns"] > 0 and st["dim"] < 40
+    assert s.trips() <= 6  # the direct back end and the oracle: 4
+    assert np.abs(V.T @ V - np.eye(V.shape[1])).max() < 1e-12
+    R = _residual(Ad, B, V, T)
+    assert np.linalg.norm(R, 2) <= 1e-8 * np.linalg.norm(B.T @ B, 2)
+
+
+def test_subspace_backend_rejected_prediction_is_loud_and_ends_the_run():
+    """The read-back of an overlapped block checks that the device met the block the host booked.  With the test hook spoiling one
+    prediction by 1 % the solve must stop at once and report a device failure (RAILS_EHIP through the C ABI), not run on to `Maximum
+    iterations` on coordinates that no longer describe the device's vectors."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, rails_amd\n"
+        "from rails_amd import problems as P\n"
+        "ctx = rails_amd.Context(device=0, seed=1)\n"
+        "A = P.laplace7(14, 12, 10)\n"
+        "op = rails_amd.HipOperatorWrapper(ctx, *A)\n"
+        "s = rails_amd.Solver(ctx, op, P.rhs(14 * 12 * 10, 6, seed=5))\n"
+        "s.set_parameters({'Restart size': 90, 'Reduced size': 40, 'Expand size': 6, 'Lanczos iterations': 8, 'Tolerance': 1e-12, 'Maximum iterations': 500})\n"
+        "s.set_option('verbose', 0)\n"
+        "s.set_option('subspace', 1)\n"
+        "try:\n"
+        "    s.solve()\n"
+        "    print('RAN ON', s.trips())\n"
+        "except rails_amd.RailsError as e:\n"
+        "    print('FAILED LOUDLY after', s.trips(), 'trips:', e)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RAILS_SUBSPACE_TEST_SPOIL_PREDICTION="3", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert "FAILED LOUDLY after" in out.stdout, out.stdout + out.stderr
+    trips = int(out.stdout.split("FAILED LOUDLY after")[1].split()[0])
+    assert trips <= 6, out.stdout  # the third overlapped block is read back at the fourth or fifth trip: the run ends there
+    assert "did not confirm its prediction" in out.stderr
