@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--cpu-one-thread", type=int, default=1, help="cpu_baseline: also time one full-size trip on a single thread (0: skip)")
     ap.add_argument("--direct-steps", type=int, default=8, help="timed trips of the extra run on the direct back end (0: skip it)")
     ap.add_argument("--spmm-variant", type=int, default=0)
+    ap.add_argument("--no-kernel-legs", action="store_true", help="skip the per-kernel timings of roofline_kernels (only the two A*X legs remain)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend; gloo = rehearsal of the multi-process path "
                     "(collectives staged through host memory, all ranks may share one GPU with --one-device)")
@@ -164,7 +165,7 @@ def main():
     assert stream, "expected a non-default stream handle"
     ctx = rails_amd.Context(device=local_rank, stream=stream, seed=args.seed)
     ctx.set_partition(rank, nranks, r0, mg)
-    ctx.enable_library_gemm()  # set-up: the basis rotation of restarts goes through rocBLAS (creating its handle takes 0.3 s, once)
+    # (the basis rotation of restarts runs on the library's own one-pass MFMA kernel, k_panel_gemm_wide: no vendor-library kernel on this path)
     collectives = "none (single GPU)"
     if nranks > 1:
         starts = np.arange(nranks + 1, dtype=np.int64) * ml
@@ -268,6 +269,103 @@ def main():
               "frac": inloop_bytes / (inloop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     log("[rank %d] in-loop SpMM %s k=%d: %.3f ms (%.1f%% of %.0f GB/s)" % (rank, inloop["kernel"], ke, inloop_ms, 100 * inloop["frac"], HBM_PEAK_GBS))
     del Xe, Ye
+    # ---- the other kernels a trip is made of, each timed live with HIP events on the library's stream at the shapes it has in the timed
+    # solve below (m rows per GPU; basis of 352 columns = the middle of a restart cycle): `roofline_kernels` of the JSON line -----------
+    roofline_kernels = [
+        {"kernel": spmm_kernel, "role": "A*X at %d columns, the workload's matrix (the headline `roofline`)" % kk, "bound": "hbm", "algorithmic_bytes": alg_bytes,
+         "avg_ms": spmm_ms, "frac": achieved / HBM_PEAK_GBS},
+        {"kernel": inloop["kernel"], "role": "the in-loop A*W at Expand size %d" % ke, "bound": "hbm", "algorithmic_bytes": inloop_bytes, "avg_ms": inloop_ms,
+         "frac": inloop["frac"]},
+    ]
+    if not args.no_kernel_legs and nranks == 1:
+        import ctypes as _C
+
+        from rails_amd._lib import check as _check
+        from rails_amd.wrappers import _p, resid_lanczos
+
+        lib = ctx.lib
+        S8 = 8
+
+        def timed(fn, reps=args.spmm_reps):
+            # per-call HIP events on the library's stream, median: a call that makes the host stall once (a first-use set-up inside the
+            # runtime: seen as one 78 ms sample of the 3.6 ms rotation) is not what the kernel takes
+            fn()
+            ctx.sync()
+            samples = []
+            for _ in range(reps):
+                ctx.timer_start()
+                fn()
+                samples.append(ctx.timer_stop())
+            return float(np.median(samples))
+
+        def randomised(n, cap=None):
+            v = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=n, capacity=cap or n)
+            for j in range(0, n, 64):
+                v.view(j, min(n, j + 64) - 1).random()
+            return v
+
+        g = np.random.default_rng(args.seed)
+        kb = 352
+        Pb = randomised(kb + 17, kb + 17 + 64)
+        # the fused update + second projection of the block Gram-Schmidt (src/StlWrapper.cpp:314-344 as one pass): X -= P C1, C2 = P'X
+        C1 = np.asfortranarray(g.uniform(-1, 1, (kb, 17)) * 1e-5)
+        _check(lib.rails_deferred_reserve(ctx.h, 8, (kb + 64) * 32), "rails_deferred_reserve")
+        ms = timed(lambda: _check(lib.rails_update_gram_deferred(ctx.h, -1.0, Pb.panel.h, 0, kb, _p(C1), kb, 17, Pb.panel.h, kb, 16, 0), "rails_update_gram_deferred"))
+        by = (kb + 2 * 17) * ml * S8
+        roofline_kernels.append({"kernel": "k_update_gram", "role": "block Gram-Schmidt: first update + second projection in one pass, k = %d, r = 17" % kb, "bound": "hbm",
+                                 "algorithmic_bytes": by, "avg_ms": ms, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        # the first projection round [P | X]' X
+        outg = np.zeros((kb + 17, 17), order="F")
+        ms = timed(lambda: lib.rails_gram(ctx.h, Pb.panel.h, 0, kb + 17, Pb.panel.h, kb, 17, _p(outg), kb + 17))
+        by = (kb + 17) * ml * S8
+        roofline_kernels.append({"kernel": "k_gram_cols", "role": "block Gram-Schmidt: first projection round [P | X]' X, %d x 17 (incl. the copy of the result to the host)" % (kb + 17),
+                                 "bound": "hbm", "algorithmic_bytes": by, "avg_ms": ms, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        # W = P Wc (materialise the expansion block)
+        Wc = np.asfortranarray(g.uniform(-1, 1, (kb, 16)) * 1e-3)
+        Wp = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=16, capacity=16)
+        ms = timed(lambda: lib.rails_panel_gemm(ctx.h, 1.0, Pb.panel.h, 0, kb, _p(Wc), kb, 16, 0.0, Wp.panel.h, 0))
+        by = (kb + 16) * ml * S8
+        roofline_kernels.append({"kernel": "k_panel_gemm", "role": "W = P Wc (materialise the expansion block), k = %d, r = 16" % kb, "bound": "hbm", "algorithmic_bytes": by,
+                                 "avg_ms": ms, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        # the restart rotation P2 = P Q: the one compute-bound product (fp64 MFMA, 78 TFLOP/s dense peak)
+        kr, rr = 324, 268
+        P2 = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=rr, capacity=rr)
+        Q = np.asfortranarray(np.linalg.qr(g.standard_normal((kr, rr)))[0])
+        ms = timed(lambda: _check(lib.rails_panel_gemm_wide(ctx.h, 1.0, Pb.panel.h, 0, kr, _p(Q), kr, rr, 0.0, P2.panel.h, 0), "rails_panel_gemm_wide"), reps=max(5, args.spmm_reps // 2))
+        fl = 2.0 * ml * kr * rr
+        roofline_kernels.append({"kernel": "k_panel_gemm_wide", "role": "restart rotation P2 = P Q, k = %d, r = %d" % (kr, rr), "bound": "mfma", "flops": fl, "avg_ms": ms,
+                                 "achieved_TFLOPs": fl / (ms * 1e-3) / 1e12, "peak_TFLOPs": 78.0, "frac": fl / (ms * 1e-3) / 1e12 / 78.0})
+        del P2, Wp
+        # the fused residual Lanczos pass of the direct back end (src/LyapunovSolver.hpp:384-434 as one pass per step)
+        kl, L = 200, args.lanczos
+        Pb.resize(2 * kl)
+        Vv, AVv = Pb.view(0, kl - 1), Pb.view(kl, 2 * kl - 1)
+        Bv = randomised(args.p)
+        Tm = g.uniform(-1, 1, (kl, kl)) * 1e-3
+        Tm = np.asfortranarray(Tm + Tm.T)
+        ms = timed(lambda: resid_lanczos(ctx, AVv, Vv, Tm, Bv, L), reps=max(3, args.spmm_reps // 4)) / (L + 1)
+        by = (2 * kl + args.p + 4) * ml * S8
+        roofline_kernels.append({"kernel": "k_lanczos_pass", "role": "direct back end: one step of the residual Lanczos recurrence, k = %d, p = %d (avg over %d passes, incl. the small kernels between them)" % (kl, args.p, L + 1),
+                                 "bound": "hbm", "algorithmic_bytes": by, "avg_ms": ms, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        del Pb, Bv, Vv, AVv
+        # the plane-sweep kernel on the pattern of configs[1] / configs[3]: 27-point stencil with the same number of rows
+        n3 = round(ml ** (1.0 / 3.0))
+        if n3 * n3 * n3 == ml:
+            from rails_amd import problems as P
+
+            As = P.stencil27(n3, n3, n3, random_values=True, seed=args.seed)
+            ops = rails_amd.HipOperatorWrapper(ctx, *As)
+            for kc in (128, 32):
+                Xs = randomised(kc)
+                Ys = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kc, capacity=kc)
+                ms = timed(lambda: ops.apply(Xs, Ys))
+                by = int(As[0][-1]) * 12 + (ml + 1) * 4 + 2 * ml * kc * S8
+                roofline_kernels.append({"kernel": ops.last_kernel(), "role": "A*X at %d columns, 27-point stencil %d^3 (configs[3]'s pattern%s)" % (kc, n3, "" if kc == 128 else ": its Expand size"),
+                                         "bound": "hbm", "algorithmic_bytes": by, "avg_ms": ms, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                del Xs, Ys
+            del ops, As
+        for rk in roofline_kernels:
+            log("[rank %d] kernel %-20s %8.3f ms  frac %.3f  (%s)" % (rank, rk["kernel"], rk["avg_ms"], rk["frac"], rk["role"]))
     traffic = None
     traffic_stale = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -342,6 +440,28 @@ def main():
             rank, 1e3 * float(np.median(dts)), 1e3 * float(dts.max()), W + 1 + int(dts.argmax()), allocs[-1] - allocs[W - 1],
             [i + 1 for i in range(W, len(allocs)) if allocs[i] != allocs[i - 1]]))
     log("[rank %d] counters: %s %s" % (rank, json.dumps(ctx.stats()), json.dumps(solver.backend_stats())))
+    # steady-state rate: whole restart cycles, whatever --warmup / --steps cut out of them.  A restart trip stands out in the stamps
+    # (shrink + re-basing: 2-3x a regular trip); the rate is taken from the first to the last restart trip of the run (warm-up included,
+    # the first three trips -- library set-up -- excluded).
+    steady_it_s, restart_trips = None, []
+    if len(stamps) > 12:
+        dall = np.diff(np.array(stamps))
+        med = float(np.median(dall[3:]))
+        restart_trips = [i for i in range(3, dall.size) if dall[i] > 1.6 * med]
+        if len(restart_trips) >= 2:
+            a, b = restart_trips[0], restart_trips[-1]
+            steady_it_s = (b - a) / float(stamps[b + 1] - stamps[a + 1])
+            log("[rank %d] steady state: restart trips %s -> %d trips in %.4f s = %.1f it/s over %d whole restart cycles" % (
+                rank, [i + 1 for i in restart_trips], b - a, stamps[b + 1] - stamps[a + 1], steady_it_s, len(restart_trips) - 1))
+    # where a trip's wall time goes on the host's side: sections in which the host computes (projected solve, residual Lanczos on
+    # coordinates, restart algebra) against sections in which it mostly waits for the device (operator apply incl. the first projection)
+    prof = solver.profile()
+    ntr = max(1, solver.trips())
+    host_keys = [k for k in prof if k in ("dense_solve", "Residual Lanczos", "Restart", "Compute VAV", "Apply B", "Expand", "Orthogonalize")]
+    wait_keys = [k for k in prof if k in ("Apply A", "Apply M")]
+    host_ms = 1e3 * sum(prof[k] for k in host_keys) / ntr
+    device_critical_ms = 1e3 * sum(prof[k] for k in wait_keys) / ntr
+    sections_ms = {k: round(1e3 * v / ntr, 4) for k, v in prof.items()}
     log("[rank %d] %d trips in %.3fs -> %.2f it/s; Lanczos estimates %.3e -> %.3e; V.N()=%d" % (rank, K, elapsed, its, hist[0], hist[-1], solver.k))
 
     # ---- GPU-busy fraction: a short run of its own on the same back end with the library's busy meter on (a pair of events around every
@@ -472,11 +592,18 @@ def main():
                        # of its own); the rest is host work with the GPU idle
                        "gpu_busy_frac": gpu_busy_frac,
                        "median_trip_ms": median_trip_ms,
+                       # rate over whole restart cycles (first to last restart trip of the run, warm-up included): independent of --warmup / --steps
+                       "steady_it_s": steady_it_s, "restart_trips": [i + 1 for i in restart_trips],
+                       # per trip, averaged over the whole solve (warm-up included): host = sections in which the host computes (projected
+                       # solve, Lanczos on coordinates, restart algebra); device_critical = sections in which it waits for the device (A * W:
+                       # materialise, SpMM, first projection round); the rest of the device's work runs behind the host's
+                       "host_ms": host_ms, "device_critical_ms": device_critical_ms, "sections_ms_per_trip": sections_ms,
                        "host_projected_solve_routes": {"smith_or_adi": sb_counts[0], "bartels_stewart": sb_counts[1]}},
             "roofline": {"bound": "hbm", "kernel": spmm_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms,
                          "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, corrected as profiles/README.md says)" if traffic else None,
                          "schedule": sweep_stats},
+            "roofline_kernels": roofline_kernels,
             "cpu_baseline": cpu,
         }
         emit(line)

@@ -304,6 +304,127 @@ void launch_pg(rails_ctx *c, double alpha, const double *X, int ldx, int k, cons
                        ldy, m, vec_ok);
 }
 
+// The restart rotation P2 = P Q (k and r in the hundreds: the one compute-bound product of the solver, src/StlWrapper.cpp:168-187 behind
+// src/LyapunovSolver.hpp:265,290) in ONE pass: a wave keeps 16 rows x ALL r <= 288 output columns in registers (TR tiles of 16 x 16, 8
+// VGPRs each), so X is read once (k_panel_gemm in 128-column slices read it once per slice and padded r = 268 to 384 columns of MFMA
+// work) and the matrix pipe does exactly ceil(r / 16) tiles per step.  C comes packed (k_pack_ct: transposed, rows of 16 TR + 4 doubles
+// -- the two k-groups a ds_read_b64 serves together fall on disjoint bank halves -- zero padded to whole chunks of 32 rows) and streams
+// through a double buffer in LDS by LDS-DMA: chunk i + 1 lands while chunk i is multiplied, one barrier per chunk, no staging loop in
+// the waves (a first form staged C with plain loads and LDS stores, 36 round trips per thread and chunk: 28 TFLOP/s).  8 waves x 16
+// rows per workgroup, one workgroup per CU (2 x 73 KiB of LDS).  X and Y must not alias.
+__global__ void k_pack_ct(const double *__restrict__ C, int k, int r, int kpad, int RL, double *__restrict__ out)
+{
+    const int64_t n = (int64_t)kpad * RL;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const int kl = (int)(q / RL), j = (int)(q % RL);
+        out[q] = (kl < k && j < r) ? C[kl + (int64_t)j * k] : 0.0;
+    }
+}
+
+template <int TR>
+__global__ __launch_bounds__(512) void k_panel_gemm_wide(double alpha, const double *__restrict__ X, int ldx, int k, const double *__restrict__ Ct /* packed, kpad x RL */,
+                                                         int r, double beta, double *__restrict__ Yp, int ldy, int64_t m, int vec_ok)
+{
+    constexpr int KC = 32, RL = 16 * TR + 4, CHUNK_B = KC * RL * 8, PIECES = CHUNK_B / 1024; // (KC * RL * 8 is a multiple of 1024 for every TR)
+    static_assert(CHUNK_B % 1024 == 0, "whole LDS-DMA pieces per chunk");
+    extern __shared__ double Cs[]; // 2 x KC x RL
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int li = lane & 15, kk = lane >> 4;
+    const int64_t r0 = ((int64_t)blockIdx.x * 8 + wave) * 16;
+    const int64_t myrow = r0 + li;
+    const bool rowok = myrow < m;
+    const int nchunks = (k + KC - 1) / KC;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)Cs;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    auto stage = [&](int chunk) { // this wave's pieces of a chunk: piece p goes to wave p % 8
+        const char *src = reinterpret_cast<const char *>(Ct) + (size_t)chunk * CHUNK_B;
+        const uint32_t dst = lds_base + (uint32_t)((chunk & 1) * CHUNK_B);
+        for (int p = wave; p < PIECES; p += 8) {
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane16), "s"(src + (size_t)p * 1024), "s"(dst + (uint32_t)(p * 1024)) : "memory");
+        }
+    };
+    v4f64 acc[TR];
+#pragma unroll
+    for (int t = 0; t < TR; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const double *xrow = X + (rowok ? myrow : m - 1) * ldx;
+    auto fetch = [&](int kcol, double *xs) {
+        if (vec_ok && kcol + 4 <= k) {
+            v2f64 t0 = *reinterpret_cast<const v2f64 *>(xrow + kcol);
+            v2f64 t1 = *reinterpret_cast<const v2f64 *>(xrow + kcol + 2);
+            xs[0] = t0.x;
+            xs[1] = t0.y;
+            xs[2] = t1.x;
+            xs[3] = t1.y;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xs[s] = (kcol + s < k) ? xrow[kcol + s] : 0.0;
+        }
+    };
+    double xa[4], xb[4];
+    stage(0);
+    fetch(4 * kk, xa);
+    fetch(16 + 4 * kk, xb);
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int ci = 0; ci < nchunks; ++ci) {
+        if (ci + 1 < nchunks) stage(ci + 1); // into the buffer every wave left at the barrier above
+        double xc[4], xd[4];
+        fetch((ci + 1) * KC + 4 * kk, xc);
+        fetch((ci + 1) * KC + 16 + 4 * kk, xd);
+        const double *cb = Cs + (size_t)(ci & 1) * (KC * RL);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double *crow = &cb[(4 * kk + s) * RL + li];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) acc[t] = mfma_f64(xa[s], crow[16 * t], acc[t]);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double *crow = &cb[(16 + 4 * kk + s) * RL + li];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) acc[t] = mfma_f64(xb[s], crow[16 * t], acc[t]);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            xa[s] = xc[s];
+            xb[s] = xd[s];
+        }
+        // the next chunk has landed (this wave's pieces; then everybody's) and nobody reads this chunk's buffer any more
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : : "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int t = 0; t < TR; ++t) {
+        const int j = 16 * t + li;
+        if (j >= r) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t row = r0 + kk + 4 * v;
+            if (row >= m) continue;
+            double *dst = Yp + row * ldy + j;
+            double val = alpha * acc[t][v];
+            if (beta != 0.0) val += beta * (*dst);
+            *dst = val;
+        }
+    }
+}
+
+// C (k x r, column-major, on the device) -> packed in `ct`; then the product
+template <int TR>
+int launch_pg_wide(rails_ctx *c, double alpha, const double *X, int ldx, int k, const double *C, int r, double beta, double *Y, int ldy, int64_t m, int vec_ok, double *ct)
+{
+    constexpr int RL = 16 * TR + 4;
+    const int kpad = (k + 31) / 32 * 32;
+    RAILS_LAUNCH(k_pack_ct, dim3((unsigned)std::min<int64_t>(512, ((int64_t)kpad * RL + 255) / 256)), dim3(256), 0, c->stream, C, k, r, kpad, RL, ct);
+    const size_t lds = (size_t)2 * 32 * RL * sizeof(double);
+    RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_panel_gemm_wide<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RAILS_LAUNCH((k_panel_gemm_wide<TR>), dim3((unsigned)((m + 127) / 128)), dim3(512), lds, c->stream, alpha, X, ldx, k, ct, r, beta, Y, ldy, m, vec_ok);
+    return RAILS_OK;
+}
+
 } // namespace
 
 int rails_gram_dev(rails_ctx *c, const double *X, int ldx, const double *Y, int ldy, int64_t m, int a, int b, double *C_dev)
@@ -799,8 +920,9 @@ bool load_rocblas()
     std::lock_guard<std::mutex> lock(g_rocblas_mutex);
     if (g_rocblas.tried) return g_rocblas.ok;
     g_rocblas.tried = true;
-    if (const char *e = getenv("RAILS_WIDE_GEMM"))
-        if (!strcmp(e, "own")) return false;
+    // opt-in since round 3: the hand-written one-pass kernel (k_panel_gemm_wide) is the default
+    const char *e = getenv("RAILS_WIDE_GEMM");
+    if (!e || strcmp(e, "rocblas")) return false;
     const char *names[] = {getenv("RAILS_ROCBLAS_LIB"), "librocblas.so", "/opt/rocm/lib/librocblas.so", "librocblas.so.5", "librocblas.so.4"};
     for (const char *n : names) {
         if (!n || !*n) continue;
@@ -881,7 +1003,8 @@ extern "C" int rails_panel_gemm_wide(rails_ctx *c, double alpha, const rails_pan
     RAILS_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     RAILS_TRY(rails_pinned_end_write(c));
     if (k >= 64 && r >= 64 && X->m < 0x7fffffffLL && rails_ctx_library_gemm_ready(c)) {
-        // row-major panels are column-major matrices transposed: Y' (r x m, ld) = alpha C' (r x k) X' (k x m, ld) + beta Y'
+        // (opt-in, RAILS_WIDE_GEMM=rocblas + rails_ctx_enable_library_gemm) row-major panels are column-major matrices transposed:
+        // Y' (r x m, ld) = alpha C' (r x k) X' (k x m, ld) + beta Y'
         const int m32 = (int)X->m;
         std::lock_guard<std::mutex> lock(g_libgemm.use);
         int rc = g_rocblas.set_stream(g_libgemm.handle, c->stream);
@@ -889,6 +1012,31 @@ extern "C" int rails_panel_gemm_wide(rails_ctx *c, double alpha, const rails_pan
         if (rc == 0) return RAILS_OK;
         rails_set_error("rails_panel_gemm_wide: rocblas_dgemm failed with status %d", rc);
         return RAILS_EHIP;
+    }
+    // slices of equal width, at most 288 columns (18 tiles of 16: what a wave's registers hold), X read once per slice
+    static const int wide_env = getenv("RAILS_PANEL_GEMM_WIDE") ? atoi(getenv("RAILS_PANEL_GEMM_WIDE")) : 1;
+    const int vec_ok = ((((uintptr_t)(X->d + xc0)) & 15) == 0 && (X->ld % 2) == 0) ? 1 : 0;
+    if (wide_env && r > 64 && k >= 32) {
+        const int nslices = (r + 287) / 288, width = ((r + nslices - 1) / nslices + 15) / 16 * 16;
+        const size_t ct_doubles = (size_t)((k + 31) / 32 * 32) * (16 * 18 + 4);
+        RAILS_TRY(rails_ws_reserve(c, (size_t)nslices * ct_doubles * sizeof(double)));
+        int slice = 0;
+        for (int j0 = 0; j0 < r; j0 += width, ++slice) {
+            const int nc = std::min(width, r - j0), tr = (nc + 31) / 32 * 2;
+            const double *Cj = c->small + (size_t)j0 * k;
+            double *Yj = Y->d + yc0 + j0, *ct = c->ws + (size_t)slice * ct_doubles;
+            switch (tr) {
+            case 2: case 4: case 6: RAILS_TRY((launch_pg_wide<6>(c, alpha, X->d + xc0, X->ld, k, Cj, nc, beta, Yj, Y->ld, X->m, vec_ok, ct))); break;
+            case 8: RAILS_TRY((launch_pg_wide<8>(c, alpha, X->d + xc0, X->ld, k, Cj, nc, beta, Yj, Y->ld, X->m, vec_ok, ct))); break;
+            case 10: RAILS_TRY((launch_pg_wide<10>(c, alpha, X->d + xc0, X->ld, k, Cj, nc, beta, Yj, Y->ld, X->m, vec_ok, ct))); break;
+            case 12: RAILS_TRY((launch_pg_wide<12>(c, alpha, X->d + xc0, X->ld, k, Cj, nc, beta, Yj, Y->ld, X->m, vec_ok, ct))); break;
+            case 14: RAILS_TRY((launch_pg_wide<14>(c, alpha, X->d + xc0, X->ld, k, Cj, nc, beta, Yj, Y->ld, X->m, vec_ok, ct))); break;
+            case 16: RAILS_TRY((launch_pg_wide<16>(c, alpha, X->d + xc0, X->ld, k, Cj, nc, beta, Yj, Y->ld, X->m, vec_ok, ct))); break;
+            default: RAILS_TRY((launch_pg_wide<18>(c, alpha, X->d + xc0, X->ld, k, Cj, nc, beta, Yj, Y->ld, X->m, vec_ok, ct))); break;
+            }
+        }
+        RAILS_HIP_CHECK(hipGetLastError());
+        return RAILS_OK;
     }
     for (int j0 = 0; j0 < r; j0 += 128) {
         const int nc = std::min(128, r - j0);

@@ -60,5 +60,15 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert "traffic" in r and r["achieved"] > 0
+    # the other kernels of a trip, each with its own live timing: bytes (or flops), average duration, fraction of its roofline
+    names = [q["kernel"] for q in d["roofline_kernels"]]
+    for want in ("k_update_gram", "k_panel_gemm_wide", "k_lanczos_pass", "k_gram_cols", "k_panel_gemm"):
+        assert want in names, names
+    for q in d["roofline_kernels"]:
+        assert q["avg_ms"] > 0 and 0 < q["frac"] < 1.5 and q["bound"] in ("hbm", "mfma") and ("algorithmic_bytes" in q or "flops" in q)
+    cfg = d["config"]
+    for key in ("steady_it_s", "restart_trips", "host_ms", "device_critical_ms", "sections_ms_per_trip", "median_trip_ms", "gpu_busy_frac", "direct_backend_it_s"):
+        assert key in cfg, key
+    assert cfg["host_ms"] > 0 and cfg["device_critical_ms"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iterations/s" and "sample" in c
