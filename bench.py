@@ -174,23 +174,40 @@ def main():
         staged = args.backend != "nccl"
         native = args.backend == "nccl" and not args.hooks
         if native:
-            # the library's own RCCL communicator: the unique id travels over the torch.distributed group that is up already
-            try:
-                box = [rails_amd.Context.rccl_unique_id() if rank == 0 else None]
+            # The library's own RCCL communicator: the unique id travels over the torch.distributed group that is up already.  Every
+            # step that can fail on one rank alone is followed by an agreement (all-reduce MIN over torch.distributed) BEFORE the next
+            # blocking collective, so that all ranks take the same branch: a rank that fell back on its own while the others sat in
+            # broadcast_object_list or ncclCommInitRank would hang the job instead of falling back to the hooks.
+            def agreed(ok):
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return int(t.item()) == 1
+
+            uid, why = None, ""
+            if rank == 0:
+                try:
+                    uid = rails_amd.Context.rccl_unique_id()
+                except Exception as e:  # librccl missing, ncclGetUniqueId failed
+                    why = str(e)
+            if agreed(rank != 0 or uid is not None):
+                box = [uid]
                 dist.broadcast_object_list(box, src=0)
-                ctx.init_rccl(box[0], nranks, rank)
-                A.set_halo(plan, None)
+                ok = True
+                try:
+                    ctx.init_rccl(box[0], nranks, rank)  # blocking: every rank is here (agreed above)
+                    A.set_halo(plan, None)
+                except Exception as e:
+                    ok, why = False, str(e)
+                if not agreed(ok):
+                    if ok:
+                        ctx.set_rccl(None)
+                    native = False
+            else:
+                native = False
+            if native:
                 collectives = "RCCL inside the library (ncclAllReduce of the projected blocks, ncclSend/ncclRecv of the ghost rows)"
-            except Exception as e:  # fall back to the hooks rather than lose the run
-                log("[rank %d] native RCCL set-up failed (%s): using the torch.distributed hooks" % (rank, e))
-                native = False
-            # every rank has to take the same path: one that fell back while the others did not would leave them waiting in a collective
-            agree = torch.tensor([1 if native else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-            if native and int(agree.item()) == 0:
-                log("[rank %d] another rank could not set up RCCL inside the library: using the torch.distributed hooks" % rank)
-                ctx.set_rccl(None)
-                native = False
+            else:
+                log("[rank %d] RCCL inside the library is not available on every rank%s: using the torch.distributed hooks" % (rank, (" (" + why + ")") if why else ""))
         if not native:
             A.set_halo(plan, partition.make_halo(plan, on_device=True, host_staged=staged))
             ctx.set_allreduce(partition.make_allreduce(on_device=True, host_staged=staged))

@@ -84,8 +84,20 @@ extern "C" int rails_ctx_destroy(rails_ctx *c)
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
     for (hipEvent_t e : c->meter_events) hipEventDestroy(e);
+    if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
+    return RAILS_OK;
+}
+
+int rails_ctx_second_stream(rails_ctx *c)
+{
+    if (c->stream2) return RAILS_OK;
+    RAILS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    RAILS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    RAILS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     return RAILS_OK;
 }
 
@@ -100,9 +112,9 @@ extern "C" int rails_ctx_stats(rails_ctx *c, char *buf, int cap)
 {
     RAILS_REQUIRE(c && buf && cap > 0, "rails_ctx_stats: bad argument");
     int n = snprintf(buf, (size_t)cap,
-                     "{\"orth_block\": %ld, \"orth_columnwise\": %ld, \"spmm_tiled\": %ld, \"spmm_planes\": %ld, \"spmm_sweep\": %ld, \"spmm_rowgather\": %ld, \"spmm_callback\": %ld, \"device_allocations\": %ld, \"allreduce\": %ld, "
+                     "{\"orth_block\": %ld, \"orth_columnwise\": %ld, \"spmm_tiled\": %ld, \"spmm_planes\": %ld, \"spmm_halo_overlapped\": %ld, \"spmm_sweep\": %ld, \"spmm_rowgather\": %ld, \"spmm_callback\": %ld, \"device_allocations\": %ld, \"allreduce\": %ld, "
                      "\"lanczos\": %ld, \"lanczos_start\": %ld, \"orth_repair\": %ld, \"update_gram_fused\": %ld, \"gpu_busy_ms\": %.3f}",
-                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_planes, c->n_spmm_sweep, c->n_spmm_rowgather, c->n_spmm_callback, c->n_dev_alloc, c->n_allreduce, c->n_lanczos, c->n_lanczos_start, c->n_orth_repair, c->n_update_gram_fused, c->gpu_busy_ms);
+                     c->n_orth_block, c->n_orth_columnwise, c->n_spmm_tiled, c->n_spmm_planes, c->n_spmm_overlapped, c->n_spmm_sweep, c->n_spmm_rowgather, c->n_spmm_callback, c->n_dev_alloc, c->n_allreduce, c->n_lanczos, c->n_lanczos_start, c->n_orth_repair, c->n_update_gram_fused, c->gpu_busy_ms);
     RAILS_REQUIRE(n > 0 && n < cap, "rails_ctx_stats: buffer too small");
     return RAILS_OK;
 }

@@ -46,6 +46,10 @@ struct rails_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second stream + fork / join events: work that may run beside the first stream's (the interior rows of a row-partitioned product
+    // while the ghost rows travel); made on first use (rails_ctx_second_stream)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int num_cu = 256;
     // RNG
     uint64_t seed = 1;
@@ -88,7 +92,7 @@ struct rails_ctx {
     double gpu_busy_ms = 0.0;
     // counters (rails_ctx_stats)
     void *lz = nullptr; // rails_lanczos_state (lanczos.hip), released by rails_lanczos_release
-    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_planes = 0, n_spmm_sweep = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_dev_alloc = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0, n_update_gram_fused = 0;
+    long n_orth_block = 0, n_orth_columnwise = 0, n_spmm_tiled = 0, n_spmm_planes = 0, n_spmm_overlapped = 0, n_spmm_sweep = 0, n_spmm_rowgather = 0, n_spmm_callback = 0, n_dev_alloc = 0, n_allreduce = 0, n_lanczos = 0, n_lanczos_start = 0, n_orth_repair = 0, n_update_gram_fused = 0;
 };
 
 // the busy meter (see rails_ctx): RAILS_LAUNCH brackets a launch, rails_stream_sync reads what has been bracketed since the last one
@@ -151,6 +155,7 @@ struct rails_csr {
     std::vector<double> h_val;
     // halo
     int64_t n_send = 0, n_ghost = 0;
+    int64_t int_lo = 0, int_hi = 0; // interior rows [int_lo, int_hi): no ghost columns (rails_csr_set_halo)
     int64_t *send_rows = nullptr;
     double *send_buf = nullptr;
     double *ext = nullptr; // [m + n_ghost] x ld_ext staging of X with ghosts appended
@@ -228,6 +233,7 @@ int rails_pinned_reserve(rails_ctx *ctx, size_t bytes);
 int rails_pinned_begin_write(rails_ctx *ctx, size_t bytes);
 int rails_pinned_end_write(rails_ctx *ctx);
 int rails_allreduce_dev(rails_ctx *ctx, double *dev, size_t n);
+int rails_ctx_second_stream(rails_ctx *ctx); // makes stream2 / ev_fork / ev_join when missing
 
 // rccl_comm.hip
 int rails_rccl_allreduce(rails_ctx *c, double *dev, size_t n);
@@ -243,6 +249,9 @@ void rails_sweep_release(rails_csr *A);
 // spmm_planes.hip: the plane-sweep kernel for structured-grid stencils; *done tells whether it computed the product
 int rails_spmm_planes(rails_ctx *c, rails_csr *A, const double *X, int ldx, double *Y, int ldy, int nc, bool aligned, bool build, bool *done);
 void rails_planes_release(rails_csr *A);
+// the interior planes of a z-slab of a grid stencil (rows without ghost columns) on stream st; *done = false: not that kind of operator
+int rails_spmm_planes_interior(rails_ctx *c, rails_csr *A, const double *X, int ldx, double *Y, int ldy, int nc, bool aligned, hipStream_t st, bool *done);
+bool planes_last_interior(const rails_csr *A);
 bool rails_detect_grid(const rails_csr *A, int64_t *nx, int64_t *ny, int64_t *nz); // spmm.hip
 // dense.hip: partial Gram into device memory (no host copy / all-reduce): C_dev (a x b col-major, ldc = a)
 int rails_gram_dev(rails_ctx *ctx, const double *X, int ldx, const double *Y, int ldy, int64_t m, int a, int b,

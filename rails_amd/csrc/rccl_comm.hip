@@ -151,15 +151,20 @@ int rails_rccl_halo(rails_ctx *c, const rails_csr *A, const double *send_buf, do
                   "rails_spmm: the ghost-row plan was made for %d ranks, the communicator has %d", (int)A->send_counts.size(), c->rccl_nranks);
     RAILS_RCCL_CHECK(g_rccl.GroupStart());
     int64_t so = 0, ro = 0;
-    for (int r = 0; r < c->rccl_nranks; ++r) {
+    ncclResult_t first = ncclSuccess; // a failing call inside the group still has to be followed by GroupEnd: an open group swallows every later call
+    for (int r = 0; r < c->rccl_nranks && first == ncclSuccess; ++r) {
         const int64_t ns = A->send_counts[r] * ncols, nr = A->recv_counts[r] * ncols;
         if (r != c->rccl_rank) {
-            if (nr) RAILS_RCCL_CHECK(g_rccl.Recv(recv_buf + ro, (size_t)nr, ncclDouble, r, (ncclComm_t)c->rccl, c->stream));
-            if (ns) RAILS_RCCL_CHECK(g_rccl.Send(send_buf + so, (size_t)ns, ncclDouble, r, (ncclComm_t)c->rccl, c->stream));
+            if (nr) first = g_rccl.Recv(recv_buf + ro, (size_t)nr, ncclDouble, r, (ncclComm_t)c->rccl, c->stream);
+            if (ns && first == ncclSuccess) first = g_rccl.Send(send_buf + so, (size_t)ns, ncclDouble, r, (ncclComm_t)c->rccl, c->stream);
         }
         so += ns;
         ro += nr;
     }
-    RAILS_RCCL_CHECK(g_rccl.GroupEnd());
+    const ncclResult_t end = g_rccl.GroupEnd();
+    if (first != ncclSuccess || end != ncclSuccess) {
+        rails_set_error("rails_spmm: the ghost-row exchange failed: %s", g_rccl.GetErrorString(first != ncclSuccess ? first : end));
+        return RAILS_ECOMM;
+    }
     return RAILS_OK;
 }

@@ -51,8 +51,10 @@ template <int LPR, int VEC, int RPG>
 __global__ __launch_bounds__(256) void k_spmm_rowgather(int64_t m, const int64_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ col, const double *__restrict__ val,
                                                         const double *__restrict__ X, int ldx, const double *__restrict__ Xg,
-                                                        int ldg, double *__restrict__ Y, int ldy, int nc, int64_t blocks_per_xcd)
+                                                        int ldg, double *__restrict__ Y, int ldy, int nc, int64_t blocks_per_xcd, int64_t mc)
 {
+    // m rows (of this launch: the operator's, or a range of them -- rowptr and Y then start at the range); mc local columns: column
+    // indices from mc on are ghost rows, taken from Xg
     constexpr int GROUPS = 256 / LPR;
     constexpr int U = 8;
     const int g = threadIdx.x / LPR;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void k_spmm_rowgather(int64_t m, const int64_t
                 const double *src[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    src[u] = (c[u] < m) ? (X + (int64_t)c[u] * ldx + cb) : (Xg + ((int64_t)c[u] - m) * ldg + cb);
+                    src[u] = (c[u] < mc) ? (X + (int64_t)c[u] * ldx + cb) : (Xg + ((int64_t)c[u] - mc) * ldg + cb);
                 if (full) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) acc.fma(a[u], src[u]);
@@ -122,13 +124,30 @@ int spmm_env(const char *name, int def)
     return e ? atoi(e) : def;
 }
 
+// rows [r0, r0 + nrows) of the operator on stream st (defaults: all rows, the context's stream).  A span is how the row-partitioned
+// product overlaps its halo exchange: interior rows on a second stream while the ghost rows travel, boundary rows afterwards.
+struct RowSpan {
+    int64_t r0 = 0, nrows = -1;
+    hipStream_t st = nullptr;
+};
+// (the busy meter brackets launches on the context's stream only)
+#define RAILS_LAUNCH_ON(st__, kern__, grid__, block__, lds__, ...)                           \
+    do {                                                                                     \
+        if ((st__) == c->stream)                                                             \
+            RAILS_LAUNCH(kern__, grid__, block__, lds__, c->stream, __VA_ARGS__);            \
+        else                                                                                 \
+            hipLaunchKernelGGL(kern__, grid__, block__, lds__, (st__), __VA_ARGS__);        \
+    } while (0)
+
 template <int LPR, int VEC>
-int launch_rg(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc)
+int launch_rg(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, const RowSpan &sp = RowSpan())
 {
+    const int64_t m_rows = sp.nrows < 0 ? A->m : sp.nrows;
+    hipStream_t st = sp.st ? sp.st : c->stream;
     constexpr int GROUPS = 256 / LPR;
     constexpr int RPG = (LPR >= 32) ? 4 : 2;
     int64_t rows_per_block = (int64_t)GROUPS * RPG;
-    int64_t grid = (A->m + rows_per_block - 1) / rows_per_block;
+    int64_t grid = (m_rows + rows_per_block - 1) / rows_per_block;
     static const int xcd_aware = spmm_env("RAILS_SPMM_XCD", 1);
     int64_t bpx = 0;
     if (xcd_aware && grid >= 64) {
@@ -136,8 +155,8 @@ int launch_rg(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const 
         grid = bpx * 8;
     }
     RAILS_REQUIRE(grid <= 0x7fffffffLL, "rails_spmm: grid too large");
-    RAILS_LAUNCH((k_spmm_rowgather<LPR, VEC, RPG>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col,
-                       A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx);
+    RAILS_LAUNCH_ON(st, (k_spmm_rowgather<LPR, VEC, RPG>), dim3((unsigned)grid), dim3(256), 0, m_rows, A->rowptr + sp.r0, A->col,
+                    A->val, X, ldx, Xg, ldg, Y + sp.r0 * ldy, ldy, nc, bpx, A->m);
     return RAILS_OK;
 }
 
@@ -152,7 +171,7 @@ template <int LPR, int RPG>
 __global__ __launch_bounds__(256) void k_spmm_rowgather_cc(int64_t m, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                            const double *__restrict__ val, const double *__restrict__ X, int ldx,
                                                            const double *__restrict__ Xg, int ldg, double *__restrict__ Y, int ldy, int nc,
-                                                           int64_t blocks_per_xcd, int lds_cap, int y_vec)
+                                                           int64_t blocks_per_xcd, int lds_cap, int y_vec, int64_t mc)
 {
     constexpr int GROUPS = 256 / LPR;
     constexpr int ROWS = GROUPS * RPG;
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(256) void k_spmm_rowgather_cc(int64_t m, const int6
                 double2_t x[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const double *src = (c[u] < m) ? (X + (int64_t)c[u] * ldx + cb) : (Xg + ((int64_t)c[u] - m) * ldg + cb);
+                    const double *src = (c[u] < mc) ? (X + (int64_t)c[u] * ldx + cb) : (Xg + ((int64_t)c[u] - mc) * ldg + cb);
                     x[u] = *reinterpret_cast<const double2_t *>(src);
                 }
 #pragma unroll
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(256) void k_spmm_rowgather_cc(int64_t m, const int6
             } else {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const double *src = (c[u] < m) ? (X + (int64_t)c[u] * ldx + cb) : (Xg + ((int64_t)c[u] - m) * ldg + cb);
+                    const double *src = (c[u] < mc) ? (X + (int64_t)c[u] * ldx + cb) : (Xg + ((int64_t)c[u] - mc) * ldg + cb);
                     acc.x = __builtin_fma(a[u], *src, acc.x);
                 }
             }
@@ -239,7 +258,7 @@ template <int RPG, bool GHOST, int LPR = 8>
 __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                      const double *__restrict__ val, const double *__restrict__ X, uint32_t ldx8,
                                                      const double *__restrict__ Xg, uint32_t ldg8, double *__restrict__ Y, int ldy, int nc,
-                                                     int64_t blocks_per_xcd, int y_vec)
+                                                     int64_t blocks_per_xcd, int y_vec, int64_t mc)
 {
     constexpr int GROUPS = 256 / LPR, ROWS = GROUPS * RPG, CAP = 2048; // LPR lanes own a row: 16 columns with 8, 32 with 16
     __shared__ double s_val[CAP];
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *_
     const int cb = l * 2;
     if (cb >= nc) return;
     const bool full = (cb + 2 <= nc);
-    const uint32_t cb8 = (uint32_t)cb * 8u, m32 = (uint32_t)m;
+    const uint32_t cb8 = (uint32_t)cb * 8u, m32 = (uint32_t)mc;
     const char *Xb = reinterpret_cast<const char *>(X), *Gb = reinterpret_cast<const char *>(Xg);
     // the address of this lane's two columns of X row c: local rows from the panel, ghost rows (c >= m, row-partitioned runs) from the
     // buffer the halo exchange filled -- a select between two bases and two strides, still 32-bit offsets
@@ -329,15 +348,20 @@ __global__ __launch_bounds__(256) void k_spmm_narrow(int64_t m, const int64_t *_
 
 template <int LPR>
 int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool y_vec = true,
-                 const char **kernel = nullptr, bool narrow_only = false)
+                 const char **kernel = nullptr, bool narrow_only = false, const RowSpan &sp = RowSpan(), int want_ghost = -1)
 {
+    // want_ghost: -1 = the operator's own form; 0 / 1 = a span whose rows have no / may have ghost columns
+    const int64_t m_rows = sp.nrows < 0 ? A->m : sp.nrows;
+    hipStream_t st = sp.st ? sp.st : c->stream;
+    const int64_t *rowptr = A->rowptr + sp.r0;
+    Y += sp.r0 * ldy;
     if (kernel) *kernel = "k_spmm_rowgather_cc";
     constexpr int GROUPS = 256 / LPR;
     constexpr int RPG = (LPR >= 32) ? 8 : (LPR >= 16 ? 4 : 2);
     constexpr int ROWS = GROUPS * RPG; // 64 rows per block
     constexpr int CC = 2 * LPR;
     const int nchunks = (nc + CC - 1) / CC;
-    const int64_t blocks = (A->m + ROWS - 1) / ROWS;
+    const int64_t blocks = (m_rows + ROWS - 1) / ROWS;
     const int64_t bpx = (blocks + 7) / 8;
     const int64_t grid = bpx * 8 * nchunks;
     RAILS_REQUIRE(grid <= 0x7fffffffLL, "rails_spmm: grid too large");
@@ -345,19 +369,19 @@ int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, con
     if ((LPR == 8 || LPR == 16) && nchunks == 1) {
         // every X row at X + c * ldx (no ghost rows; a rectangular operator's extra rows follow X in the same panel) within 32-bit byte offsets
         static const int narrow_fast = spmm_env("RAILS_SPMM_NARROW_FAST", 1);
-        const bool flat = (A->n_ghost == 0 && !A->rect) || (Xg == X + (int64_t)A->m * ldx && ldg == ldx);
+        const bool flat = want_ghost == 0 || (want_ghost < 0 && ((A->n_ghost == 0 && !A->rect) || (Xg == X + (int64_t)A->m * ldx && ldg == ldx)));
         const bool small = A->ncols_ext < (1 << 24) && (int64_t)ldx * 8 < (1 << 24) && (int64_t)ldg * 8 < (1 << 24);
         if (narrow_fast && small && flat && (uint64_t)A->ncols_ext * (uint64_t)ldx * 8u < 0xffffff00ull) {
-            RAILS_LAUNCH((k_spmm_narrow<RPG, false, (LPR == 16 ? 16 : 8)>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, X, 0u, Y,
-                         ldy, nc, bpx, y_vec ? 1 : 0);
+            RAILS_LAUNCH_ON(st, (k_spmm_narrow<RPG, false, (LPR == 16 ? 16 : 8)>), dim3((unsigned)grid), dim3(256), 0, m_rows, rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, X, 0u, Y,
+                            ldy, nc, bpx, y_vec ? 1 : 0, A->m);
             if (kernel) *kernel = "k_spmm_narrow";
             return RAILS_OK;
         }
         // row-partitioned runs: columns >= m are ghost rows in the halo buffer (16-byte aligned rows there too)
         if (narrow_fast && small && !flat && !A->rect && (uint64_t)A->m * (uint64_t)ldx * 8u < 0xffffff00ull &&
             (uint64_t)(A->ncols_ext - A->m) * (uint64_t)ldg * 8u < 0xffffff00ull ) {
-            RAILS_LAUNCH((k_spmm_narrow<RPG, true, (LPR == 16 ? 16 : 8)>), dim3((unsigned)grid), dim3(256), 0, c->stream, A->m, A->rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, Xg,
-                         (uint32_t)ldg * 8u, Y, ldy, nc, bpx, y_vec ? 1 : 0);
+            RAILS_LAUNCH_ON(st, (k_spmm_narrow<RPG, true, (LPR == 16 ? 16 : 8)>), dim3((unsigned)grid), dim3(256), 0, m_rows, rowptr, A->col, A->val, X, (uint32_t)ldx * 8u, Xg,
+                            (uint32_t)ldg * 8u, Y, ldy, nc, bpx, y_vec ? 1 : 0, A->m);
             if (kernel) *kernel = "k_spmm_narrow";
             return RAILS_OK;
         }
@@ -366,8 +390,8 @@ int launch_rg_cc(rails_ctx *c, const rails_csr *A, const double *X, int ldx, con
         if (kernel) *kernel = nullptr;
         return RAILS_OK;
     }
-    RAILS_LAUNCH((k_spmm_rowgather_cc<LPR, RPG>), dim3((unsigned)grid), dim3(256), (size_t)lds_cap * 12, c->stream, A->m, A->rowptr,
-                       A->col, A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx, lds_cap, y_vec ? 1 : 0);
+    RAILS_LAUNCH_ON(st, (k_spmm_rowgather_cc<LPR, RPG>), dim3((unsigned)grid), dim3(256), (size_t)lds_cap * 12, m_rows, rowptr,
+                    A->col, A->val, X, ldx, Xg, ldg, Y, ldy, nc, bpx, lds_cap, y_vec ? 1 : 0, A->m);
     return RAILS_OK;
 }
 
@@ -385,16 +409,37 @@ int rowgather_chunk(const rails_csr *A, int nc)
 }
 
 template <int VEC>
-int dispatch_rg(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc)
+int dispatch_rg(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, const RowSpan &sp = RowSpan())
 {
     int need = (nc + VEC - 1) / VEC;
-    if (need >= 64) return launch_rg<64, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc);
-    if (need > 16) return launch_rg<32, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc);
-    if (need > 8) return launch_rg<16, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc);
-    if (need > 4) return launch_rg<8, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc);
-    if (need > 2) return launch_rg<4, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc);
-    if (need > 1) return launch_rg<2, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc);
-    return launch_rg<1, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc);
+    if (need >= 64) return launch_rg<64, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, sp);
+    if (need > 16) return launch_rg<32, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, sp);
+    if (need > 8) return launch_rg<16, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, sp);
+    if (need > 4) return launch_rg<8, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, sp);
+    if (need > 2) return launch_rg<4, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, sp);
+    if (need > 1) return launch_rg<2, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, sp);
+    return launch_rg<1, VEC>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, sp);
+}
+
+// The rows of a span with the row kernels (what the serial path below picks for the same width): bitwise the same product row by row,
+// whichever launch a row belongs to.  ghost: the span's rows may have ghost columns (taken from Xg).
+int spmm_span(rails_ctx *c, const rails_csr *A, const double *X, int ldx, const double *Xg, int ldg, double *Y, int ldy, int nc, bool x_vec2, bool y_vec2,
+              const RowSpan &sp, bool ghost, const char **kname = nullptr)
+{
+    if (sp.nrows <= 0) return RAILS_OK;
+    if (kname) *kname = "k_spmm_rowgather";
+    static const int narrow_env = spmm_env("RAILS_SPMM_NARROW_CC", 1);
+    if (x_vec2 && narrow_env && A->variant != 3 && nc > 8 && nc <= 32 && A->max_row_nnz <= 64) {
+        const char *k = nullptr;
+        if (nc <= 16)
+            RAILS_TRY((launch_rg_cc<8>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, y_vec2, &k, false, sp, ghost ? 1 : 0)));
+        else
+            RAILS_TRY((launch_rg_cc<16>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, y_vec2, &k, false, sp, ghost ? 1 : 0)));
+        if (kname) *kname = k;
+        return RAILS_OK;
+    }
+    if (nc >= 2) return dispatch_rg<2>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, sp);
+    return dispatch_rg<1>(c, A, X, ldx, Xg, ldg, Y, ldy, nc, sp);
 }
 
 int build_transpose(rails_csr *A)
@@ -586,6 +631,24 @@ extern "C" int rails_csr_set_halo(rails_csr *A, int64_t n_send, const int64_t *s
     A->n_ghost = n_ghost;
     A->halo = fn;
     A->halo_user = user;
+    // the interior rows: the contiguous range in the middle of the block whose rows reference no ghost column (row blocks of banded and
+    // grid operators keep their boundary rows at the two ends).  Their product does not wait for the exchange (rails_spmm).
+    A->int_lo = 0;
+    A->int_hi = A->m;
+    if (n_ghost > 0) {
+        const int64_t m = A->m, mid = m / 2;
+        for (int64_t r = 0; r < m; ++r) {
+            bool boundary = false;
+            for (int64_t p2 = A->h_rowptr[r]; p2 < A->h_rowptr[r + 1] && !boundary; ++p2) boundary = A->h_col[p2] >= m;
+            if (!boundary) continue;
+            if (r < mid)
+                A->int_lo = r + 1;
+            else {
+                A->int_hi = r;
+                break;
+            }
+        }
+    }
     if (n_send) {
         RAILS_HIP_CHECK(hipMalloc((void **)&A->send_rows, (size_t)n_send * sizeof(int64_t)));
         RAILS_HIP_CHECK(hipMemcpy(A->send_rows, send_rows, (size_t)n_send * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -684,6 +747,27 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
             RAILS_HIP_CHECK(hipMalloc((void **)&A->ext, gbytes));
             A->ext_cap = gbytes;
         }
+        // Overlap: the interior rows' product runs on the context's second stream while the ghost rows are packed, exchanged and
+        // waited for on the first; the boundary rows follow the exchange, and the first stream then waits for the interior.  Row by
+        // row the same kernels as the serial order below (`RAILS_SPMM_HALO_OVERLAP=0`): the result is bitwise the same.
+        const int overlap_env = spmm_env("RAILS_SPMM_HALO_OVERLAP", 1); // (read per product: the tests switch it inside one process)
+        const bool x_vec2o = (xc0 & 1) == 0 && (X->ld % 2 == 0) && (nc % 2 == 0), y_vec2o = (yc0 & 1) == 0 && (Y->ld % 2 == 0);
+        const bool overlap = overlap_env && A->n_ghost > 0 && !A->rect && (A->variant == 0 || A->variant == 1 || A->variant == 3) &&
+                             A->int_hi - A->int_lo >= A->m / 2 && A->int_hi - A->int_lo >= 1024;
+        if (overlap) {
+            RAILS_TRY(rails_ctx_second_stream(c));
+            RAILS_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
+            RAILS_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            RowSpan in;
+            in.r0 = A->int_lo;
+            in.nrows = A->int_hi - A->int_lo;
+            in.st = c->stream2;
+            bool planes_done = false;
+            RAILS_TRY(rails_spmm_planes_interior(c, A, Xp, X->ld, Yp, Y->ld, nc, x_vec2o && y_vec2o, c->stream2, &planes_done));
+            if (!planes_done) RAILS_TRY(spmm_span(c, A, Xp, X->ld, Xp, X->ld, Yp, Y->ld, nc, x_vec2o, y_vec2o, in, false));
+            RAILS_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
+            c->n_spmm_overlapped++;
+        }
         if (A->n_send) {
             int64_t total = A->n_send * nc;
             int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)c->num_cu * 8);
@@ -698,6 +782,27 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         } else {
             RAILS_REQUIRE(c->rccl, "rails_spmm: ghost rows but neither a halo hook nor an RCCL communicator");
             RAILS_TRY(rails_rccl_halo(c, A, A->send_buf, A->ext, nc));
+        }
+        if (overlap) {
+            const bool gvec = x_vec2o; // (ghost rows are packed with ld = nc: even, 16-byte aligned rows when nc is even)
+            RowSpan lo, hi;
+            lo.r0 = 0;
+            lo.nrows = A->int_lo;
+            hi.r0 = A->int_hi;
+            hi.nrows = A->m - A->int_hi;
+            const char *kb = "k_spmm_rowgather";
+            RAILS_TRY(spmm_span(c, A, Xp, X->ld, A->ext, nc, Yp, Y->ld, nc, gvec, y_vec2o, lo, true, &kb));
+            RAILS_TRY(spmm_span(c, A, Xp, X->ld, A->ext, nc, Yp, Y->ld, nc, gvec, y_vec2o, hi, true, &kb));
+            RAILS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            // (what ran: the kernel of the boundary rows, and of the interior rows where that is another one)
+            const bool narrow = !strcmp(kb, "k_spmm_narrow");
+            if (planes_last_interior(A))
+                A->last_kernel = narrow ? "k_spmm_narrow + k_spmm_planes (halo overlapped)" : "k_spmm_rowgather + k_spmm_planes (halo overlapped)";
+            else
+                A->last_kernel = narrow ? "k_spmm_narrow (halo overlapped)" : (!strcmp(kb, "k_spmm_rowgather_cc") ? "k_spmm_rowgather_cc (halo overlapped)" : "k_spmm_rowgather (halo overlapped)");
+            c->n_spmm_rowgather++;
+            RAILS_HIP_CHECK(hipGetLastError());
+            return RAILS_OK;
         }
         Xg = A->ext;
         ldg = nc;

@@ -29,6 +29,7 @@ struct PlanesArgs {
     int gx, gy, gz;
     int ldx, ldy, nc;
     int npx, npy, nseg, seglen;
+    int z_lo, z_hi; // output planes of this launch (the whole grid, or the interior planes of a z-slab whose end planes have ghost columns)
     int wg_per_xcd, nwg;
 };
 
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(64 * WX * WY) void k_spmm_planes(const double *__re
     if (id >= a.nwg) return;
     const int px = id % a.npx, t = id / a.npx, py = t % a.npy, seg = t / a.npy;
     const int x0 = px * PX, y0 = py * PY;
-    const int zs = seg * a.seglen, ze = min(a.gz, zs + a.seglen);
+    const int zs = a.z_lo + seg * a.seglen, ze = min(a.z_hi, zs + a.seglen);
     const int col0 = blockIdx.y * (2 * LPR), ncc = min(2 * LPR, a.nc - col0);
     const bool lane_on = 2 * ll < ncc;
     const int64_t plane_x = (int64_t)a.gx * a.gy * a.ldx;  // doubles per plane of X
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(64 * WX * WY) void k_spmm_planes(const double *__re
 struct rails_planes_plan {
     bool ok = false;
     bool cross = false;
+    bool last_interior = false; // the last product ran the interior planes only (row-partitioned operator, rails_spmm_planes_interior)
     int gx = 0, gy = 0, gz = 0;
+    int z_lo = 0, z_hi = 0; // output planes the records are complete for: all of them, or a z-slab's planes without ghost columns
     double *cf = nullptr;
     double *zero = nullptr;
 };
@@ -218,27 +221,31 @@ void rails_planes_release(rails_csr *A)
 // that qualifies can have it from its first product on.
 namespace {
 __global__ __launch_bounds__(256) void k_planes_build(int64_t m, int gx, int gy, int gz, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                      const double *__restrict__ val, double *__restrict__ cf, unsigned *__restrict__ flags)
+                                                      const double *__restrict__ val, double *__restrict__ cf, unsigned *__restrict__ flags, int64_t v_lo, int64_t v_hi)
 {
+    // rows [v_lo, v_hi) must be complete stencil rows; the others (the end planes of a z-slab: they have ghost columns and are not
+    // computed from the records) only contribute the entries that multiply local X rows
     const int64_t plane = (int64_t)gx * gy;
     unsigned f = 0;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(r % gx), y = (int)((r / gx) % gy), z = (int)(r / plane);
         const int ex = 1 + (x > 0) + (x < gx - 1), ey = 1 + (y > 0) + (y < gy - 1), ez = 1 + (z > 0) + (z < gz - 1);
         const int64_t p0 = rowptr[r], p1 = rowptr[r + 1];
-        if (p1 - p0 != ex * ey * ez) f |= 4u;     // not the complete 27-point neighbourhood
-        if (p1 - p0 != ex + ey + ez - 2) f |= 8u; // not the complete 7-point one
+        const bool checked = r >= v_lo && r < v_hi;
+        if (checked && p1 - p0 != ex * ey * ez) f |= 4u;     // not the complete 27-point neighbourhood
+        if (checked && p1 - p0 != ex + ey + ez - 2) f |= 8u; // not the complete 7-point one
         int64_t prev = -1;
         for (int64_t p = p0; p < p1; ++p) {
             const int64_t cc = col[p];
-            if (cc <= prev || cc >= m) f |= 1u; // (sorted, no duplicates: with the count above every neighbour is there exactly once)
+            if (checked && (cc <= prev || cc >= m)) f |= 1u; // (sorted, no duplicates: with the count above every neighbour is there exactly once)
             prev = cc;
+            if (cc >= m) continue;
             const int dx = (int)(cc % gx) - x, dy = (int)((cc / gx) % gy) - y, dz = (int)(cc / plane) - z;
             if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) {
-                f |= 1u;
+                if (checked) f |= 1u;
                 continue;
             }
-            if ((dx != 0) + (dy != 0) + (dz != 0) > 1) f |= 2u;
+            if (checked && (dx != 0) + (dy != 0) + (dz != 0) > 1) f |= 2u;
             // the entry multiplies X row (x+dx, y+dy, z+dz): record of grid column (x, y) at X plane z + dz, output plane slot dz + 1
             cf[((int64_t)(z + dz) * plane + (int64_t)y * gx + x) * PL_REC + (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] = val[p];
         }
@@ -251,10 +258,17 @@ static int planes_build(rails_ctx *c, rails_csr *A)
 {
     A->planes = new rails_planes_plan();
     rails_planes_plan *P = A->planes;
-    if (A->n_ghost > 0 || A->rect || A->m != A->ncols_ext || A->nnz == 0) return RAILS_OK;
+    if (A->rect || A->nnz == 0 || (A->n_ghost == 0 && A->m != A->ncols_ext)) return RAILS_OK;
     int64_t gx = 0, gy = 0, gz = 0;
     if (!rails_detect_grid(A, &gx, &gy, &gz)) return RAILS_OK;
     if (gx * gy * gz != A->m || gx > 0x7fff || gy > 0x7fff || gz > 0x3fffffff) return RAILS_OK;
+    // a row block with ghost columns: a z-slab whose interior rows (rails_csr_set_halo) are whole planes
+    int64_t v_lo = 0, v_hi = A->m;
+    if (A->n_ghost > 0) {
+        v_lo = A->int_lo;
+        v_hi = A->int_hi;
+        if (v_lo % (gx * gy) || v_hi % (gx * gy) || v_hi - v_lo < gx * gy) return RAILS_OK;
+    }
     const size_t cf_bytes = (size_t)A->m * PL_REC * sizeof(double);
     unsigned *flags = nullptr;
     RAILS_HIP_CHECK(hipMalloc((void **)&P->cf, cf_bytes));
@@ -264,7 +278,7 @@ static int planes_build(rails_ctx *c, rails_csr *A)
     RAILS_HIP_CHECK(hipMemsetAsync(P->cf, 0, cf_bytes, c->stream));
     RAILS_HIP_CHECK(hipMemsetAsync(P->zero, 0, 1024 + 64, c->stream));
     const int grid = (int)std::min<int64_t>((A->m + 255) / 256, (int64_t)c->num_cu * 16);
-    RAILS_LAUNCH(k_planes_build, dim3(grid), dim3(256), 0, c->stream, A->m, (int)gx, (int)gy, (int)gz, A->rowptr, A->col, A->val, P->cf, flags);
+    RAILS_LAUNCH(k_planes_build, dim3(grid), dim3(256), 0, c->stream, A->m, (int)gx, (int)gy, (int)gz, A->rowptr, A->col, A->val, P->cf, flags, v_lo, v_hi);
     unsigned f = 0;
     RAILS_HIP_CHECK(hipMemcpyAsync(&f, flags, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     RAILS_HIP_CHECK(rails_stream_sync(c));
@@ -278,6 +292,8 @@ static int planes_build(rails_ctx *c, rails_csr *A)
     P->gy = (int)gy;
     P->gz = (int)gz;
     P->cross = cross;
+    P->z_lo = (int)(v_lo / (gx * gy));
+    P->z_hi = (int)(v_hi / (gx * gy));
     P->ok = true;
     return RAILS_OK;
 }
@@ -289,7 +305,7 @@ static int planes_env(const char *name, int def)
 }
 
 template <int LPR, int RW, int WX, int WY>
-static int planes_launch(rails_ctx *c, const rails_planes_plan *P, const double *X, int ldx, double *Y, int ldy, int nc)
+static int planes_launch(rails_ctx *c, const rails_planes_plan *P, const double *X, int ldx, double *Y, int ldy, int nc, hipStream_t st)
 {
     constexpr int G = 64 / LPR, NW = WX * WY, PX = RW * WX, PY = WY * G, HXP = (PX + 2 + G - 1) / G * G, NXS = (PY + 2) * (HXP / G);
     constexpr int NCF = (PY * PX * PL_REC * 8 + 1023) / 1024;
@@ -306,10 +322,13 @@ static int planes_launch(rails_ctx *c, const rails_planes_plan *P, const double 
     const int nchunks = (nc + 2 * LPR - 1) / (2 * LPR);
     // z segments: the workgroups of a launch run in rounds of one per CU; a segment of len planes costs len + 2 steps (+ ~2 of start-up)
     static const int env_seg = planes_env("RAILS_PLANES_SEG", 0);
-    int best_len = P->gz;
+    const int nz = P->z_hi - P->z_lo;
+    a.z_lo = P->z_lo;
+    a.z_hi = P->z_hi;
+    int best_len = nz;
     double best = 1e300;
-    for (int nseg = 1; nseg <= std::min(P->gz, 256); ++nseg) {
-        const int len = (P->gz + nseg - 1) / nseg, ns = (P->gz + len - 1) / len;
+    for (int nseg = 1; nseg <= std::min(nz, 256); ++nseg) {
+        const int len = (nz + nseg - 1) / nseg, ns = (nz + len - 1) / len;
         const double wgs = (double)a.npx * a.npy * ns * nchunks;
         const double rounds = std::ceil(wgs / (double)c->num_cu);
         const double cost = rounds * (len + 4);
@@ -318,51 +337,90 @@ static int planes_launch(rails_ctx *c, const rails_planes_plan *P, const double 
             best_len = len;
         }
     }
-    if (env_seg > 0) best_len = std::min(env_seg, P->gz);
+    if (env_seg > 0) best_len = std::min(env_seg, nz);
     a.seglen = best_len;
-    a.nseg = (P->gz + best_len - 1) / best_len;
+    a.nseg = (nz + best_len - 1) / best_len;
     a.nwg = a.npx * a.npy * a.nseg;
     a.wg_per_xcd = a.nwg >= 64 ? (a.nwg + 7) / 8 : 0;
     const unsigned grid = a.wg_per_xcd ? (unsigned)a.wg_per_xcd * 8u : (unsigned)a.nwg;
     const size_t lds = (size_t)(2 * NXS + 3 * NCF) * 1024;
     if (P->cross) {
         RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_planes<LPR, RW, WX, WY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        RAILS_LAUNCH((k_spmm_planes<LPR, RW, WX, WY, true>), dim3(grid, (unsigned)nchunks), dim3(64 * NW), lds, c->stream, X, Y, P->cf, P->zero, a);
+        if (st == c->stream)
+            RAILS_LAUNCH((k_spmm_planes<LPR, RW, WX, WY, true>), dim3(grid, (unsigned)nchunks), dim3(64 * NW), lds, c->stream, X, Y, P->cf, P->zero, a);
+        else
+            hipLaunchKernelGGL((k_spmm_planes<LPR, RW, WX, WY, true>), dim3(grid, (unsigned)nchunks), dim3(64 * NW), lds, st, X, Y, P->cf, P->zero, a);
     } else {
         RAILS_HIP_CHECK(hipFuncSetAttribute((const void *)k_spmm_planes<LPR, RW, WX, WY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        RAILS_LAUNCH((k_spmm_planes<LPR, RW, WX, WY, false>), dim3(grid, (unsigned)nchunks), dim3(64 * NW), lds, c->stream, X, Y, P->cf, P->zero, a);
+        if (st == c->stream)
+            RAILS_LAUNCH((k_spmm_planes<LPR, RW, WX, WY, false>), dim3(grid, (unsigned)nchunks), dim3(64 * NW), lds, c->stream, X, Y, P->cf, P->zero, a);
+        else
+            hipLaunchKernelGGL((k_spmm_planes<LPR, RW, WX, WY, false>), dim3(grid, (unsigned)nchunks), dim3(64 * NW), lds, st, X, Y, P->cf, P->zero, a);
     }
     return RAILS_OK;
 }
 
-// *done tells whether the kernel computed the product; `build` = the plan may be made now (a host pass over the matrix)
+static int planes_dispatch(rails_ctx *c, const rails_planes_plan *P, const double *X, int ldx, double *Y, int ldy, int nc, hipStream_t st)
+{
+    // lanes per row by the panel's width; patch shapes by what the LDS holds (two X planes + three planes of records)
+    static const int shape = planes_env("RAILS_PLANES_SHAPE", 0);
+    if (nc <= 16)
+        RAILS_TRY((planes_launch<8, 2, 4, 2>(c, P, X, ldx, Y, ldy, nc, st)));
+    else if (nc <= 32)
+        RAILS_TRY((planes_launch<16, 2, 4, 3>(c, P, X, ldx, Y, ldy, nc, st)));
+    else if (nc <= 64)
+        RAILS_TRY((planes_launch<32, 2, 4, 4>(c, P, X, ldx, Y, ldy, nc, st)));
+    else if (shape == 1)
+        RAILS_TRY((planes_launch<64, 4, 2, 4>(c, P, X, ldx, Y, ldy, nc, st)));
+    else if (shape == 2)
+        RAILS_TRY((planes_launch<64, 3, 2, 5>(c, P, X, ldx, Y, ldy, nc, st)));
+    else if (shape == 3)
+        RAILS_TRY((planes_launch<32, 2, 4, 4>(c, P, X, ldx, Y, ldy, nc, st)));
+    else
+        RAILS_TRY((planes_launch<64, 2, 4, 4>(c, P, X, ldx, Y, ldy, nc, st)));
+    return RAILS_OK;
+}
+
+static bool planes_shape_ok(const rails_planes_plan *P, int ldx, int ldy, int nc, bool aligned)
+{
+    if (!P->ok || !aligned || nc < 2 || (nc & 1)) return false;
+    return (int64_t)P->gx * P->gy * std::max(std::max(ldx, ldy), PL_REC) * 8 < 0x7fffffffLL; // 32-bit offsets inside a plane
+}
+
+// *done tells whether the kernel computed the product; `build` = the plan may be made now (one pass over the matrix on the device)
 int rails_spmm_planes(rails_ctx *c, rails_csr *A, const double *X, int ldx, double *Y, int ldy, int nc, bool aligned, bool build, bool *done)
 {
     *done = false;
+    if (A->n_ghost > 0) return RAILS_OK; // (row blocks with ghost columns: rails_spmm_planes_interior)
     if (!A->planes) {
         if (!build) return RAILS_OK;
         RAILS_TRY(planes_build(c, A));
     }
-    const rails_planes_plan *P = A->planes;
-    if (!P->ok || !aligned || nc < 2 || (nc & 1)) return RAILS_OK;
-    if ((int64_t)P->gx * P->gy * std::max(std::max(ldx, ldy), PL_REC) * 8 >= 0x7fffffffLL) return RAILS_OK; // 32-bit offsets inside a plane
-    // lanes per row by the panel's width; patch shapes by what the LDS holds (two X planes + three planes of records)
-    static const int shape = planes_env("RAILS_PLANES_SHAPE", 0);
-    if (nc <= 16)
-        RAILS_TRY((planes_launch<8, 2, 4, 2>(c, P, X, ldx, Y, ldy, nc)));
-    else if (nc <= 32)
-        RAILS_TRY((planes_launch<16, 2, 4, 3>(c, P, X, ldx, Y, ldy, nc)));
-    else if (nc <= 64)
-        RAILS_TRY((planes_launch<32, 2, 4, 4>(c, P, X, ldx, Y, ldy, nc)));
-    else if (shape == 1)
-        RAILS_TRY((planes_launch<64, 4, 2, 4>(c, P, X, ldx, Y, ldy, nc)));
-    else if (shape == 2)
-        RAILS_TRY((planes_launch<64, 3, 2, 5>(c, P, X, ldx, Y, ldy, nc)));
-    else if (shape == 3)
-        RAILS_TRY((planes_launch<32, 2, 4, 4>(c, P, X, ldx, Y, ldy, nc)));
-    else
-        RAILS_TRY((planes_launch<64, 2, 4, 4>(c, P, X, ldx, Y, ldy, nc)));
+    rails_planes_plan *P = A->planes;
+    if (!planes_shape_ok(P, ldx, ldy, nc, aligned)) return RAILS_OK;
+    RAILS_TRY(planes_dispatch(c, P, X, ldx, Y, ldy, nc, c->stream));
+    P->last_interior = false;
     A->last_kernel = "k_spmm_planes";
     *done = true;
     return RAILS_OK;
 }
+
+// The interior planes of a row block that is a z-slab of a grid stencil (BASELINE configs[3]'s partition): the planes without ghost
+// columns, on stream st -- while the ghost planes travel (rails_spmm).  The two end planes are the caller's (row kernels, after the exchange).
+int rails_spmm_planes_interior(rails_ctx *c, rails_csr *A, const double *X, int ldx, double *Y, int ldy, int nc, bool aligned, hipStream_t st, bool *done)
+{
+    *done = false;
+    static const int on = planes_env("RAILS_SPMM_PLANES", 1);
+    if (!on || A->n_ghost == 0 || A->variant != 0) return RAILS_OK;
+    if (!A->planes) RAILS_TRY(planes_build(c, A));
+    rails_planes_plan *P = A->planes;
+    P->last_interior = false;
+    if (!planes_shape_ok(P, ldx, ldy, nc, aligned)) return RAILS_OK;
+    RAILS_TRY(planes_dispatch(c, P, X, ldx, Y, ldy, nc, st));
+    P->last_interior = true;
+    c->n_spmm_planes++;
+    *done = true;
+    return RAILS_OK;
+}
+
+bool planes_last_interior(const rails_csr *A) { return A->planes && A->planes->last_interior; }

@@ -36,6 +36,9 @@ def test_two_ranks_share_one_gpu():
     assert "global 120000" in line2["config"]["workload"]
     assert len(first2) == 2 and first2[0] == first2[1]  # both ranks hold the same replicated small quantities
     assert err2.count("ghosts=") == 2 and "ghosts=0" not in err2  # rows really crossed the partition
+    # ... and the products overlapped their exchange: interior rows on the second stream while the ghost rows travelled
+    overl = [int(m.group(1)) for m in re.finditer(r'"spmm_halo_overlapped": (\d+)', err2)]
+    assert len(overl) >= 2 and min(overl) > 0, overl
     # (numerical equivalence with the undivided problem is what tests/test_gpu_partition.py checks: bench.py generates every
     # rank's row block from its own seed, so there is no single-process twin of this run)
     last = [float(m.group(1)) for m in re.finditer(r"Lanczos estimates [0-9.e+-]+ -> ([0-9.e+-]+);", err2)]
