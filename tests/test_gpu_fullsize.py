@@ -159,10 +159,11 @@ def test_solver_full_size_both_back_ends(ctx, c3):
         assert k <= PARAMS["Restart size"]
         assert np.abs(T - T.T).max() <= 1e-12 * np.abs(T).max()
         Vd = MV(ctx, data=V)
-        # the reference does not re-orthogonalise after restarts (:270) either.  Measured: 5e-15 on the coordinate-space back end; on the
-        # direct one 0.9e-10 .. 1.2e-10 depending on which kernel rotated the basis at the restarts (the library GEMM where a process has
-        # asked for it, the hand-written one otherwise: scripts/orth_probe.py) -- the CholQR of the nearly dependent A*V blocks sets it
-        assert np.abs(Vd.dot(Vd) - np.eye(k)).max() <= (1e-12 if subspace else 5e-10)
+        # the reference does not re-orthogonalise after restarts (:270) either.  Measured (scripts/probe_bounds.py, three seeds): 3e-15 .. 5e-15
+        # on the coordinate-space back end; 0.07e-10 .. 1.2e-10 on the direct one, whose restarts rotate V in place with the hand-written
+        # panel GEMM (the vendor GEMM is opt-in since round 3 and no test asks for it) -- the CholQR of the nearly dependent A*V blocks
+        # sets that level, the rotation preserves it
+        assert np.abs(Vd.dot(Vd) - np.eye(k)).max() <= (1e-12 if subspace else 2e-10)
         assert s.relative_residual() < PARAMS["Tolerance"]
         # the reference's own acceptance, re-evaluated independently: ||R||_2 < tol * ||B||_2^2.  The solver's value is a
         # 20-step Lanczos estimate (a lower bound that is tight for the dominant eigenvalue); allow it a factor 2.

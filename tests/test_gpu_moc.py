@@ -54,8 +54,11 @@ def test_moc_schur_generalized_solve(subspace, oracle):
     assert out["ret"] == 0
     Xo = out["V"] @ out["T"] @ out["V"].T
     assert np.linalg.norm(X - Xo) / np.linalg.norm(Xo) < 50 * PARAMS["Tolerance"]
-    # several hundred trips of a slowly converging solve (575 on the CPU): the two free-running trajectories agree in what they reach (above),
-    # their lengths within a factor of 1.5 (the operator's products differ in summation order between the device and scipy)
-    assert out["trips"] / 1.5 <= s.trips() <= 1.5 * out["trips"]
+    # Several hundred trips of a slowly converging solve with `Lanczos iterations` (10) > 2 + p: the chaotic regime of the reference's own
+    # recurrence (oracle/README.md), in which the residual estimates of two implementations part from the first trips on (measured: they
+    # differ by more than 1e-6 at trip 1 on both back ends), so the trajectories cannot be compared trip by trip; what they reach agrees
+    # (above).  Their lengths, measured (scripts/probe_bounds.py): oracle 575 trips, direct back end 499 (0.87x), coordinate-space back
+    # end 722 (1.26x) -- asserted with a margin of 10 % on those ratios.
+    assert out["trips"] / 1.4 <= s.trips() <= 1.4 * out["trips"]
     s.close()
     ctx.close()
