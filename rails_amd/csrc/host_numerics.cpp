@@ -90,24 +90,25 @@ bool try_open(const std::string &path)
     // rest of it: one 40-90 ms trip some 100 ms after the first host LAPACK call of a solve (BENCH_r01: "slowest 42 ms").
     // openblas_set_num_threads() after the fact does not stop them, so the count is given through the environment for the
     // duration of the dlopen (and restored: other BLAS users of the process keep their own setting).
+    // setenv is not safe against getenv in other threads of the process, so the window is kept as small as it can be: nothing is touched
+    // when the library is in the process already (its threads exist: RTLD_NOLOAD probe), a variable the application has set itself is
+    // left alone (its choice stands -- `OPENBLAS_NUM_THREADS=1 python bench.py` never gets here), and what is set is set once, under
+    // g_lp_mutex, before the dlopen, and taken back right after.  An application with threads of its own that cannot tolerate even
+    // that calls rails_host_lapack_init (or creates its first context) before it starts them, or exports the variable.
     int want_threads = 1;
     if (const char *e = getenv("RAILS_LAPACK_THREADS")) want_threads = atoi(e) > 0 ? atoi(e) : 1;
-    static const char *thread_vars[] = {"OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", nullptr};
-    std::string saved[2];
-    bool had[2] = {false, false};
-    for (int i = 0; thread_vars[i]; ++i) {
-        if (const char *old = getenv(thread_vars[i])) {
-            had[i] = true;
-            saved[i] = old;
-        }
-        setenv(thread_vars[i], std::to_string(want_threads).c_str(), 1);
-    }
-    void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-    for (int i = 0; thread_vars[i]; ++i) {
-        if (had[i])
-            setenv(thread_vars[i], saved[i].c_str(), 1);
-        else
-            unsetenv(thread_vars[i]);
+    void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!h) {
+        static const char *thread_vars[] = {"OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", nullptr};
+        bool mine[2] = {false, false};
+        for (int i = 0; thread_vars[i]; ++i)
+            if (!getenv(thread_vars[i])) {
+                mine[i] = true;
+                setenv(thread_vars[i], std::to_string(want_threads).c_str(), 1);
+            }
+        h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        for (int i = 0; thread_vars[i]; ++i)
+            if (mine[i]) unsetenv(thread_vars[i]);
     }
     if (!h) return false;
     HostLapack L;

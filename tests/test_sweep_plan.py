@@ -114,3 +114,8 @@ def test_compiler_stays_out_of_the_assembly_registers():
     spec.loader.exec_module(mod)
     kernels, bad = mod.check()
     assert kernels >= 2 and not bad, bad[:5]
+    # the object that ships, not only a separate compile: metadata notes of the code objects inside the built librails_hip.so
+    nb, badb = mod.check_built()
+    assert nb >= 2 and not badb, badb[:5]
+    meta = mod.kernel_metadata()
+    assert all(v.get("private_segment_fixed_size", 0) == 0 for k, v in meta.items() if "k_spmm_planes" in k or "k_panel_gemm_wide" in k)  # no spills in the new kernels
