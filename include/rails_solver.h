@@ -32,7 +32,9 @@ int rails_solver_destroy(rails_solver *s);
 int rails_solver_set_parameter(rails_solver *s, const char *name, double value);
 int rails_solver_apply_parameters(rails_solver *s, int *code);
 
-/* extensions: "mass" (use M, generalized equation), "verbose", "max_trips", "projected_lanczos" (M = I only: carry the
+/* extensions: "mass" (use M, generalized equation), "mass_orthogonalisation" (with mass: keep V M-orthonormal, V'MV = I, so that the
+ * projected equation is the standard one -- `opts.ortho = 'M'` of matlab/RAILSsolver.m:38-41,384,583-597; default 0: orthonormal V and the
+ * generalized projected equation by Cholesky reduction), "verbose", "max_trips", "projected_lanczos" (M = I only: carry the
  * residual Lanczos recurrence in coefficient space, see rails/HipSolverOps.hpp), "subspace" (default 1: run the solver template on the
  * coordinate-space back end of rails/SubspaceWrappers.hpp -- all multivectors as coordinates in one orthonormal device basis;
  * 0: the direct back end of rails/HipWrappers.hpp) */

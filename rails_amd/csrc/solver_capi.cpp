@@ -47,6 +47,7 @@ struct rails_solver {
     int64_t m_local = 0, m_global = 0;
     bool has_M = false;
     bool mass = false;
+    bool ortho_m = false; // V kept M-orthonormal (matlab/RAILSsolver.m opts.ortho = 'M'); needs mass
     rails_trip_fn trip_fn = nullptr;
     void *trip_user = nullptr;
     // coordinate-space back end (rails/SubspaceWrappers.hpp): used by solve() when asked for and applicable
@@ -133,6 +134,13 @@ extern "C" int rails_solver_set_option(rails_solver *s, const char *name, double
         }
         s->mass = value != 0.0;
         s->solver->use_mass_matrix(s->mass);
+    } else if (n == "mass_orthogonalisation" || n == "ortho_m") {
+        if (value != 0.0 && !s->mass) {
+            rails_set_error("rails_solver_set_option: mass_orthogonalisation needs the option mass (set it first)");
+            return RAILS_EINVAL;
+        }
+        s->ortho_m = value != 0.0;
+        s->solver->use_mass_orthogonalisation(s->ortho_m);
     } else if (n == "verbose") {
         s->verbose = value != 0.0;
         s->solver->set_verbose(s->verbose);
@@ -195,6 +203,7 @@ static int solve_in_coordinates(rails_solver *s)
     solver.set_verbose(s->verbose);
     solver.set_max_trips(s->max_trips);
     solver.use_mass_matrix(s->mass);
+    solver.use_mass_orthogonalisation(s->ortho_m);
     if (s->trip_fn) solver.set_trip_callback([s](int trip) { s->trip_fn(s->trip_user, trip); });
     solver.set_failure_check([basis]() { return basis->failed; }); // a latched failure of the basis ends the run at the next trip
     rails::SubspaceMultiVector Vc(basis, 1);

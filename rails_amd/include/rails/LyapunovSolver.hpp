@@ -226,6 +226,10 @@ public:
 
     // extensions (not in the reference): generalized M, quiet mode, bounded runs, instrumentation
     void use_mass_matrix(bool on) { mass_ = on; }
+    // `opts.ortho = 'M'` of matlab/RAILSsolver.m:38-41,538-618: V is kept M-orthonormal (V'MV = I), so the projected equation is the
+    // standard one (`lyap(VAV, VBV)`, :384) instead of the generalized one; needs use_mass_matrix(true) and a symmetric definite M
+    void use_mass_orthogonalisation(bool on) { ortho_m_ = on; }
+    bool mass_orthogonalisation() const { return mass_ && ortho_m_; }
     void set_verbose(bool on) { verbose_ = on; }
     void set_max_trips(int n) { trip_budget_ = n; }
     // residual Lanczos carried in the (2k+p+1)-dimensional coefficient space where the backend supports it
@@ -459,7 +463,10 @@ private:
                 V_.resize(capacity_);
                 V_.resize(1);
                 V_.random();
-                V_.orthogonalize();
+                if (s_.mass_orthogonalisation())
+                    m_orthogonalize(0);
+                else
+                    V_.orthogonalize();
             } else if (V_.N() != capacity_)
                 reserve_columns(V_, capacity_);
             fresh_ = MultiVector(V_); // a deep copy: every column is still to be multiplied (:123)
@@ -527,10 +534,10 @@ private:
                 put(b_, k, 0, cross);
                 for (int j = 0; j < cross.N(); ++j)
                     for (int i = 0; i < cross.M(); ++i) b_(j, k + i) = cross(i, j);
-                if (s_.mass_) put(m_, k, 0, fresh_.dot(MV_.view(0, k - 1)));
+                if (s_.mass_ && !s_.ortho_m_) put(m_, k, 0, fresh_.dot(MV_.view(0, k - 1)));
             }
             put(a_, 0, k, V_.dot(AW));
-            if (s_.mass_) put(m_, 0, k, V_.dot(MW));
+            if (s_.mass_ && !s_.ortho_m_) put(m_, 0, k, V_.dot(MW));
             put(b_, k, k, BtW.dot(BtW));
             BtV_.push_back(BtW);
         }
@@ -538,10 +545,10 @@ private:
         void reduce()
         {
             ScopedTimer t(&s_.sections_, "dense_solve");
-            if (s_.mass_)
+            if (s_.mass_ && !s_.ortho_m_)
                 s_.generalized_dense_solve(a_, b_, m_, T_);
             else
-                s_.dense_solve(a_, b_, T_); // :209
+                s_.dense_solve(a_, b_, T_); // :209; with V'MV = I the generalized equation projects to the standard one (RAILSsolver.m:384)
         }
 
         // largest modulus among the Ritz values of the residual operator (:211-221)
@@ -633,11 +640,47 @@ private:
                 ScopedTimer t(&s_.sections_, "Expand");
                 ritz.append_to(V_, leading, add);
             }
+            int kept = add;
             {
                 ScopedTimer t(&s_.sections_, "Orthogonalize");
-                V_.orthogonalize();
+                if (s_.mass_orthogonalisation())
+                    kept = m_orthogonalize(width_before);
+                else
+                    V_.orthogonalize();
             }
-            fresh_ = V_.view(width_before, width_before + add - 1);
+            fresh_ = V_.view(width_before, width_before + kept - 1);
+        }
+
+        // Modified Gram-Schmidt in the M inner product on the columns from `first` on (matlab/RAILSsolver.m:583-597, Morth with M): every
+        // new column is normalised, M-projected against all columns before it (twice: the reference's single sweep leaves a component
+        // of relative size eps * cond, and V'MV = I is what makes the projected equation the standard one), M-normalised, and DROPPED
+        // when less than 1e-8 of it is left (:592-594) -- V then grows by fewer columns than asked for.  Returns the columns kept.
+        int m_orthogonalize(int first)
+        {
+            int n = V_.N(), j = first;
+            while (j < n) {
+                MultiVector v = V_.view(j);
+                v /= v.norm();
+                if (j > 0) {
+                    MultiVector const before = V_.view(0, j - 1);
+                    for (int pass = 0; pass < 2; ++pass) {
+                        MultiVector const Mv = s_.op_M_ * v;
+                        v -= before * before.dot(Mv);
+                    }
+                }
+                MultiVector const Mv = s_.op_M_ * v;
+                DenseMatrix const vMv = v.dot(Mv);
+                const double energy = std::abs(vMv(0, 0)); // (a definite M of either sign: the MOC data's mass entries are negative)
+                const double nrm = std::sqrt(energy);
+                if (!(nrm >= 1e-8)) { // nothing new in this column: the later ones move up
+                    for (int l = j + 1; l < n; ++l) V_.view(l - 1) = V_.view(l);
+                    V_.resize(--n);
+                    continue;
+                }
+                v /= nrm;
+                ++j;
+            }
+            return n - first;
         }
     };
     friend class Run;
@@ -654,6 +697,7 @@ protected:
     Settings settings_;
 
     bool mass_ = false;
+    bool ortho_m_ = false;
     bool verbose_ = true;
     int trip_budget_ = 0;
     int trips_ = 0;

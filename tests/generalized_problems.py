@@ -70,7 +70,8 @@ def check_acceptance(A, Md, B, V, T, res_estimate, trips, trip_bound):
 CASES = {
     "Laplace_64": ("laplace", 64, 2, {}, 64 - 10),
     "Laplace_256": ("laplace", 256, 4, {}, 256 - 10),
-    "morth_256": ("laplace", 256, 1, {}, 256 - 10),  # test_opts.m:181-195 runs this class with opts.ortho = 'M' (V'MV = I); here: the Cholesky reduction of section 8(f).1
+    "morth_256": ("laplace", 256, 1, {}, 256 - 10),  # test_opts.m:181-195: opts.ortho = 'M' (V'MV = I, standard projected equation): the GPU test sets the solver's
+                                                      # mass_orthogonalisation option; the CPU oracle has the Cholesky reduction only and runs the same problem with it
     "random_64": ("random", 64, 1, {"Minimize solution space": 0}, None),  # opts.restart_upon_convergence = false, no bound on iter
 }
 

@@ -23,8 +23,13 @@ def test_generalized_acceptance(oracle, name, subspace):
     s.set_option("verbose", 0)
     s.set_option("mass", 1)
     s.set_option("subspace", subspace)
+    morth = name.startswith("morth")
+    if morth:
+        s.set_option("mass_orthogonalisation", 1)  # opts.ortho = 'M' (matlab/RAILSsolver.m:583-597): V'MV = I, `lyap(VAV, VBV)`
     code, V, T = s.solve()
     assert code == 0
+    if morth:
+        assert np.abs(V.T @ (Md[:, None] * V) - np.eye(V.shape[1])).max() < 1e-10
     true_res = G.check_acceptance(A, Md, B, V, T, abs(s.history()[-1]), s.trips(), bound)
     # the library's own evaluation of the generalized residual (Frobenius norms, from panel products without forming X: the squares of
     # three terms combined, so its floor is ~sqrt(eps) of ||B B'||) agrees with the dense one
@@ -37,6 +42,7 @@ def test_generalized_acceptance(oracle, name, subspace):
     assert out["ret"] == 0
     Xo = out["V"] @ out["T"] @ out["V"].T
     assert np.linalg.norm(X - Xo) <= 50 * params["Tolerance"] * np.linalg.norm(Xo)
-    assert abs(s.trips() - int(out["trips"])) <= max(3, int(out["trips"]) // 5)
+    if not morth:  # (the oracle runs the other formulation of that case: another trajectory to the same solution)
+        assert abs(s.trips() - int(out["trips"])) <= max(3, int(out["trips"]) // 5)
     s.close()
     ctx.close()
