@@ -506,7 +506,8 @@ def test_deferred_small_results(ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,k,r,r2,xoff", [(50000, 100, 17, 16, 0), (60007, 352, 17, 16, 0), (40000, 300, 16, 16, 2), (30000, 420, 17, 12, 0),
-                                           (20000, 64, 5, 3, 0), (50000, 200, 17, 16, 1), (50000, 120, 20, 18, 0), (3000, 90, 17, 16, 0)])
+                                           (20000, 64, 5, 3, 0), (50000, 200, 17, 16, 1), (50000, 120, 20, 18, 0), (3000, 90, 17, 16, 0),
+                                           (45001, 353, 17, 16, 0), (33000, 130, 17, 16, 0), (33003, 410, 17, 16, 4), (4100, 128, 1, 1, 0), (70000, 255, 9, 9, 6)])
 def test_update_and_second_projection_in_one_pass(ctx, m, k, r, r2, xoff):
     """rails_update_gram_deferred (include/rails_hip.h): Y += alpha X C, then slot <- X' Y[:, :r2], as one pass over X (k_update_gram:
     16 MFMA columns + the 17th on the vector unit; odd window offsets, 20 columns or few rows take the two separate kernels) against numpy.  The second sweep of the reference's block Gram-Schmidt (src/StlWrapper.cpp:314-344)."""
