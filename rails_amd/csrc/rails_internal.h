@@ -246,6 +246,9 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
                      bool force, bool *done);
 int rails_sweep_prepare(rails_ctx *c, rails_csr *A, int nc, bool *fits); // the schedule for nc columns, now
 void rails_sweep_release(rails_csr *A);
+// the interior rows of a row-partitioned operator as a sweep of their own (on stream st, beside the halo exchange)
+int rails_spmm_sweep_interior(rails_ctx *c, rails_csr *A, const double *X, int ldx, double *Y, int ldy, int nc, bool aligned, hipStream_t st, bool *done);
+int rails_sweep_prepare_interior(rails_ctx *c, rails_csr *A, int nc, bool *fits);
 // spmm_planes.hip: the plane-sweep kernel for structured-grid stencils; *done tells whether it computed the product
 int rails_spmm_planes(rails_ctx *c, rails_csr *A, const double *X, int ldx, double *Y, int ldy, int nc, bool aligned, bool build, bool *done);
 void rails_planes_release(rails_csr *A);

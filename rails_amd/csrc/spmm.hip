@@ -691,6 +691,10 @@ extern "C" int rails_csr_prepare(rails_ctx *c, rails_csr *A, int trans, int nc, 
         bool fits = false;
         RAILS_TRY(rails_sweep_prepare(c, A, nc, &fits));
         if (kernel_ready) *kernel_ready = fits ? 1 : 0;
+    } else if (A->variant == 0 && A->n_ghost > 0 && !rails_csr_is_grid(A)) { // row-partitioned: the schedule of the interior rows
+        bool fits = false;
+        RAILS_TRY(rails_sweep_prepare_interior(c, A, nc, &fits));
+        if (kernel_ready) *kernel_ready = fits ? 1 : 0;
     }
     return RAILS_OK;
 }
@@ -752,6 +756,7 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
         // row the same kernels as the serial order below (`RAILS_SPMM_HALO_OVERLAP=0`): the result is bitwise the same.
         const int overlap_env = spmm_env("RAILS_SPMM_HALO_OVERLAP", 1); // (read per product: the tests switch it inside one process)
         const bool x_vec2o = (xc0 & 1) == 0 && (X->ld % 2 == 0) && (nc % 2 == 0), y_vec2o = (yc0 & 1) == 0 && (Y->ld % 2 == 0);
+        bool interior_sweep = false;
         const bool overlap = overlap_env && A->n_ghost > 0 && !A->rect && (A->variant == 0 || A->variant == 1 || A->variant == 3) &&
                              A->int_hi - A->int_lo >= A->m / 2 && A->int_hi - A->int_lo >= 1024;
         if (overlap) {
@@ -762,9 +767,11 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
             in.r0 = A->int_lo;
             in.nrows = A->int_hi - A->int_lo;
             in.st = c->stream2;
-            bool planes_done = false;
+            bool planes_done = false, sweep_done = false;
             RAILS_TRY(rails_spmm_planes_interior(c, A, Xp, X->ld, Yp, Y->ld, nc, x_vec2o && y_vec2o, c->stream2, &planes_done));
-            if (!planes_done) RAILS_TRY(spmm_span(c, A, Xp, X->ld, Xp, X->ld, Yp, Y->ld, nc, x_vec2o, y_vec2o, in, false));
+            if (!planes_done) RAILS_TRY(rails_spmm_sweep_interior(c, A, Xp, X->ld, Yp, Y->ld, nc, x_vec2o && y_vec2o, c->stream2, &sweep_done));
+            interior_sweep = sweep_done;
+            if (!planes_done && !sweep_done) RAILS_TRY(spmm_span(c, A, Xp, X->ld, Xp, X->ld, Yp, Y->ld, nc, x_vec2o, y_vec2o, in, false));
             RAILS_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
             c->n_spmm_overlapped++;
         }
@@ -796,7 +803,9 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
             RAILS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
             // (what ran: the kernel of the boundary rows, and of the interior rows where that is another one)
             const bool narrow = !strcmp(kb, "k_spmm_narrow");
-            if (planes_last_interior(A))
+            if (interior_sweep)
+                A->last_kernel = "k_spmm_rowgather + k_spmm_sweep (halo overlapped)";
+            else if (planes_last_interior(A))
                 A->last_kernel = narrow ? "k_spmm_narrow + k_spmm_planes (halo overlapped)" : "k_spmm_rowgather + k_spmm_planes (halo overlapped)";
             else
                 A->last_kernel = narrow ? "k_spmm_narrow (halo overlapped)" : (!strcmp(kb, "k_spmm_rowgather_cc") ? "k_spmm_rowgather_cc (halo overlapped)" : "k_spmm_rowgather (halo overlapped)");

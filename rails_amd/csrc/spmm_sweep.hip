@@ -241,12 +241,17 @@ void free_plan(DevPlan *d)
 struct rails_sweep_cache {
     std::map<int, DevPlan *> by_chunks;
     std::map<int, int> asked; // products of that width seen in automatic mode before the schedule exists
+    // row-partitioned operators: schedules of the INTERIOR rows [int_lo, int_hi) (no ghost columns: a rectangular operator over the local
+    // X rows), whose product runs beside the halo exchange (rails_spmm_sweep_interior)
+    std::map<int, DevPlan *> interior;
+    std::map<int, int> asked_interior;
 };
 
 void rails_sweep_release(rails_csr *A)
 {
     if (!A->sweep) return;
     for (auto &kv : A->sweep->by_chunks) free_plan(kv.second);
+    for (auto &kv : A->sweep->interior) free_plan(kv.second);
     delete A->sweep;
     A->sweep = nullptr;
 }
@@ -255,10 +260,13 @@ void rails_sweep_release(rails_csr *A)
 static constexpr int SWEEP_W = 8, SWEEP_G = 22;
 
 // The schedule of A for n_chunks column chunks, built (host, a second per million rows) and copied to the device when missing.
-static int ensure_plan(rails_ctx *c, rails_csr *A, int n_chunks, DevPlan **out)
+static int ensure_plan(rails_ctx *c, rails_csr *A, int n_chunks, DevPlan **out, bool interior = false)
 {
     if (!A->sweep) A->sweep = new rails_sweep_cache();
-    DevPlan *&d = A->sweep->by_chunks[n_chunks];
+    DevPlan *&d = interior ? A->sweep->interior[n_chunks] : A->sweep->by_chunks[n_chunks];
+    // the rows the schedule covers and the X rows they may reference: the whole (square) operator, or the interior rows over the local rows
+    const int64_t plan_rows = interior ? A->int_hi - A->int_lo : A->m, plan_cols = interior ? A->m : A->ncols_ext;
+    const int64_t *plan_rowptr = A->h_rowptr.data() + (interior ? A->int_lo : 0);
     if (!d) {
         d = new DevPlan();
         rails_sweep_params prm;
@@ -273,10 +281,10 @@ static int ensure_plan(rails_ctx *c, rails_csr *A, int n_chunks, DevPlan **out)
         if (getenv("RAILS_SWEEP_SLACK")) prm.level_slack = atoi(getenv("RAILS_SWEEP_SLACK"));
         if (getenv("RAILS_SWEEP_ENTRY_TRIPS")) prm.entry_trips = atoi(getenv("RAILS_SWEEP_ENTRY_TRIPS")) == 4 ? 4 : 2; // 4: entries of whole units (k_spmm_sweep)
         if (getenv("RAILS_SWEEP_ABLATE") && atoi(getenv("RAILS_SWEEP_ABLATE"))) prm.entry_trips = 4;                  // (the experiment builds take those)
-        bool built = rails_sweep_plan_build(prm, A->m, A->ncols_ext, A->h_rowptr.data(), A->h_col.data(), A->h_val.data(), d->host);
+        bool built = rails_sweep_plan_build(prm, plan_rows, plan_cols, plan_rowptr, A->h_col.data(), A->h_val.data(), d->host);
         if (!built && prm.entry_trips == 2) { // heavy rows: twice the entries do not fit a step's record; whole units may
             prm.entry_trips = 4;
-            built = rails_sweep_plan_build(prm, A->m, A->ncols_ext, A->h_rowptr.data(), A->h_col.data(), A->h_val.data(), d->host);
+            built = rails_sweep_plan_build(prm, plan_rows, plan_cols, plan_rowptr, A->h_col.data(), A->h_val.data(), d->host);
         }
         if (built) {
             RAILS_TRY(up(c, &d->part_row0, d->host.part_row0));
@@ -393,6 +401,64 @@ int rails_spmm_sweep(rails_ctx *c, rails_csr *A, const double *X, int ldx, const
 #endif
     RAILS_HIP_CHECK(hipGetLastError());
     A->last_kernel = launched;
+    c->n_spmm_sweep++;
+    *done = true;
+    return RAILS_OK;
+}
+
+// The interior rows of a row-partitioned operator (rails_csr_set_halo: rows [int_lo, int_hi) reference local X rows only) as a sweep of
+// their own, on stream st while the ghost rows travel (rails_spmm).  prepare_only: build the schedule if the shape qualifies.
+static bool sweep_interior_shape_ok(const rails_ctx *c, const rails_csr *A, int nc, bool aligned)
+{
+    const int n_chunks = nc / 16;
+    if (!(aligned && nc % 16 == 0 && nc >= 64 && n_chunks <= 32 && 32 % n_chunks == 0 && c->num_cu >= 256 && A->n_ghost > 0 && !A->rect && A->m < 0x7fffffffLL)) return false;
+    const int64_t phases = 32 / n_chunks, rows = A->int_hi - A->int_lo, part_rows = rows / 8;
+    return A->window_rows > 0 && A->window_rows + 256 <= (phases - 1) * 2816 && rows >= 8 * phases * 2816 &&
+           (double)phases * (double)(part_rows + A->window_rows + 1024) <= 8.0 * (double)part_rows;
+}
+
+int rails_sweep_prepare_interior(rails_ctx *c, rails_csr *A, int nc, bool *fits)
+{
+    *fits = false;
+    if (!sweep_interior_shape_ok(c, A, nc, true)) return RAILS_OK;
+    DevPlan *d = nullptr;
+    RAILS_TRY(ensure_plan(c, A, nc / 16, &d, true));
+    *fits = d->ok && d->host.efficiency >= 0.4 && d->host.staged_rows_per_row <= 8.0;
+    return RAILS_OK;
+}
+
+int rails_spmm_sweep_interior(rails_ctx *c, rails_csr *A, const double *X, int ldx, double *Y, int ldy, int nc, bool aligned, hipStream_t st, bool *done)
+{
+    *done = false;
+    if (A->variant != 0 || !sweep_interior_shape_ok(c, A, nc, aligned)) return RAILS_OK;
+    const int n_chunks = nc / 16;
+    if (!A->sweep) A->sweep = new rails_sweep_cache();
+    if (!A->sweep->interior.count(n_chunks)) {
+        static const int after = getenv("RAILS_SWEEP_AFTER") ? atoi(getenv("RAILS_SWEEP_AFTER")) : 16;
+        if (++A->sweep->asked_interior[n_chunks] < after) return RAILS_OK;
+    }
+    DevPlan *d = nullptr;
+    RAILS_TRY(ensure_plan(c, A, n_chunks, &d, true));
+    if (!d->ok || d->host.efficiency < 0.4 || d->host.staged_rows_per_row > 8.0) return RAILS_OK;
+    SweepArgs a;
+    a.ldx = ldx;
+    a.ldg = ldx;
+    a.ldy = ldy;
+    a.m = A->m;     // X rows below this index come from X: all of them (the interior rows have no ghost columns)
+    a.ncols = A->m;
+    a.parts = 8;
+    a.n_chunks = n_chunks;
+    a.phases = 32 / n_chunks;
+    a.ablate = 0;
+    a.layout = 0;
+    double *Yi = Y + A->int_lo * ldy;
+    if (d->host.p.entry_trips == 2)
+        hipLaunchKernelGGL((k_spmm_sweep_h2<SWEEP_W, SWEEP_G>), dim3(256), dim3(SWEEP_W * 64), 0, st, a, d->part_row0, d->sweep0, d->nsteps, d->hdr_off, d->batch_off, d->codes,
+                           d->vals, d->offs, X, X, Yi);
+    else
+        hipLaunchKernelGGL((k_spmm_sweep<SWEEP_W, SWEEP_G>), dim3(256), dim3(SWEEP_W * 64), 0, st, a, d->part_row0, d->sweep0, d->nsteps, d->hdr_off, d->batch_off, d->codes,
+                           d->vals, d->offs, X, X, Yi);
+    RAILS_HIP_CHECK(hipGetLastError());
     c->n_spmm_sweep++;
     *done = true;
     return RAILS_OK;

@@ -278,3 +278,46 @@ def test_halo_overlap_is_bitwise_the_serial_product(oracle, monkeypatch, kind, n
         assert "halo overlapped" in results["1"][r]["k128"]
         if kind != "banded":
             assert "k_spmm_planes" in results["1"][r]["k128"] and "k_spmm_planes" in results["1"][r]["k16"]
+
+
+def test_interior_rows_of_a_banded_block_take_the_sweep_kernel(monkeypatch):
+    """At panel width the interior rows of a row-partitioned banded operator (no ghost columns: a rectangular operator over the local X
+    rows) run as a sweep of their own beside the halo exchange -- at N > 1 the A*X of the roofline leg no longer falls back to the
+    row-gather kernel -- and the panel is bitwise the serial row-kernel product."""
+    from rails_amd import partition
+    from rails_amd import problems as P
+    from rails_amd.wrappers import HipMultiVectorWrapper as MV
+
+    nranks, m = 2, 260000
+    A = P.banded_random(m, 27, 1000, seed=3)
+    X = np.random.default_rng(8).uniform(-1, 1, (m, 128))
+    starts = partition.row_ranges(m, nranks)
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RAILS_SPMM_HALO_OVERLAP", mode)
+        ranks = Ranks(nranks)
+
+        def work(r):
+            ctx, op, plan = _rank_setup(ranks, r, starts, A, seed=5)
+            r0, r1 = int(starts[r]), int(starts[r + 1])
+            if mode == "0":
+                op.set_variant(1)
+            else:
+                op.prepare(128)  # set-up: the schedule of the interior rows
+            Y = op.apply(MV(ctx, data=X[r0:r1]))
+            out = dict(Y=Y.to_host(), kernel=op.last_kernel(), stats=ctx.stats())
+            ctx.close()
+            return out
+
+        results[mode] = ranks.run(work)
+    Yo = np.vstack([results["1"][r]["Y"] for r in range(nranks)])
+    Ys = np.vstack([results["0"][r]["Y"] for r in range(nranks)])
+    assert np.array_equal(Yo, Ys), np.abs(Yo - Ys).max()
+    for r in range(nranks):
+        assert "k_spmm_sweep" in results["1"][r]["kernel"] and results["1"][r]["stats"]["spmm_sweep"] == 1
+    rows = np.random.default_rng(1).choice(m, 3000, replace=False)
+    rp, col, val = A
+    ref = np.zeros((rows.size, 128))
+    for k, i in enumerate(rows):
+        ref[k] = val[rp[i]:rp[i + 1]] @ X[col[rp[i]:rp[i + 1]]]
+    assert np.abs(Yo[rows] - ref).max() <= 4e-14 * np.sqrt(27) * np.abs(ref).max()
