@@ -156,6 +156,7 @@ struct rails_csr {
     // halo
     int64_t n_send = 0, n_ghost = 0;
     int64_t int_lo = 0, int_hi = 0; // interior rows [int_lo, int_hi): no ghost columns (rails_csr_set_halo)
+    int64_t window_rows_int = 0;    // window_rows of the interior rows alone
     int64_t *send_rows = nullptr;
     double *send_buf = nullptr;
     double *ext = nullptr; // [m + n_ghost] x ld_ext staging of X with ghosts appended

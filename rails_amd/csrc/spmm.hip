@@ -648,6 +648,20 @@ extern "C" int rails_csr_set_halo(rails_csr *A, int64_t n_send, const int64_t *s
                 break;
             }
         }
+        // the sliding window of the interior rows alone (the boundary rows' ghost columns sit behind the local ones: they would inflate it)
+        const int64_t nint = A->int_hi - A->int_lo, stride = std::max<int64_t>(1, nint / 4096);
+        int64_t sum = 0, cnt = 0;
+        for (int64_t r = A->int_lo; r < A->int_hi; r += stride) {
+            if (A->h_rowptr[r + 1] == A->h_rowptr[r]) continue;
+            int32_t lo = A->h_col[A->h_rowptr[r]], hi = lo;
+            for (int64_t q = A->h_rowptr[r]; q < A->h_rowptr[r + 1]; ++q) {
+                lo = std::min(lo, A->h_col[q]);
+                hi = std::max(hi, A->h_col[q]);
+            }
+            sum += (int64_t)hi - lo + 1;
+            cnt++;
+        }
+        A->window_rows_int = cnt ? sum / cnt : 0;
     }
     if (n_send) {
         RAILS_HIP_CHECK(hipMalloc((void **)&A->send_rows, (size_t)n_send * sizeof(int64_t)));

@@ -413,8 +413,8 @@ static bool sweep_interior_shape_ok(const rails_ctx *c, const rails_csr *A, int 
     const int n_chunks = nc / 16;
     if (!(aligned && nc % 16 == 0 && nc >= 64 && n_chunks <= 32 && 32 % n_chunks == 0 && c->num_cu >= 256 && A->n_ghost > 0 && !A->rect && A->m < 0x7fffffffLL)) return false;
     const int64_t phases = 32 / n_chunks, rows = A->int_hi - A->int_lo, part_rows = rows / 8;
-    return A->window_rows > 0 && A->window_rows + 256 <= (phases - 1) * 2816 && rows >= 8 * phases * 2816 &&
-           (double)phases * (double)(part_rows + A->window_rows + 1024) <= 8.0 * (double)part_rows;
+    return A->window_rows_int > 0 && A->window_rows_int + 256 <= (phases - 1) * 2816 && rows >= 8 * phases * 2816 &&
+           (double)phases * (double)(part_rows + A->window_rows_int + 1024) <= 8.0 * (double)part_rows;
 }
 
 int rails_sweep_prepare_interior(rails_ctx *c, rails_csr *A, int nc, bool *fits)

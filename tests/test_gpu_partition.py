@@ -288,7 +288,7 @@ def test_interior_rows_of_a_banded_block_take_the_sweep_kernel(monkeypatch):
     from rails_amd import problems as P
     from rails_amd.wrappers import HipMultiVectorWrapper as MV
 
-    nranks, m = 2, 260000
+    nranks, m = 3, 390000  # (the middle rank has ghost rows on both sides)
     A = P.banded_random(m, 27, 1000, seed=3)
     X = np.random.default_rng(8).uniform(-1, 1, (m, 128))
     starts = partition.row_ranges(m, nranks)
