@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--subspace", type=int, default=1, help="1 (default): coordinate-space back end (rails/SubspaceWrappers.hpp); 0: direct panels")
     ap.add_argument("--spmm-only", action="store_true", help="kernel experiment: only the A*X timing, for several column counts")
     ap.add_argument("--spmm-cols", default="128", help="comma list of column counts for --spmm-only")
-    ap.add_argument("--spmm-variants", default="", help="--spmm-only: comma list of operator variants to time (default: 1, 2, 7, or --spmm-variant)")
+    ap.add_argument("--spmm-variants", default="", help="--spmm-only: comma list of operator variants to time (default: 1, 2, 7, 9, or --spmm-variant)")
     ap.add_argument("--spmm-pad", type=int, default=0, help="--spmm-only: extra panel capacity (columns), i.e. a row stride that is not a power of two")
     args = ap.parse_args()
     _protect_stdout()
@@ -227,7 +227,7 @@ def main():
             X = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk + args.spmm_pad)
             Y = rails_amd.HipMultiVectorWrapper(ctx, m=ml, n=kk, capacity=kk + args.spmm_pad)
             X.random()
-            variants = [int(v) for v in args.spmm_variants.split(",")] if args.spmm_variants else ((1, 2, 7) if args.spmm_variant == 0 else (args.spmm_variant,))
+            variants = [int(v) for v in args.spmm_variants.split(",")] if args.spmm_variants else ((1, 2, 7, 9) if args.spmm_variant == 0 else (args.spmm_variant,))
             for variant in variants:
                 A.set_variant(variant)
                 A.prepare(kk)

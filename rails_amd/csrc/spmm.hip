@@ -782,7 +782,7 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
             in.nrows = A->int_hi - A->int_lo;
             in.st = c->stream2;
             bool planes_done = false, sweep_done = false;
-            RAILS_TRY(rails_spmm_planes_interior(c, A, Xp, X->ld, Yp, Y->ld, nc, x_vec2o && y_vec2o, c->stream2, &planes_done));
+            RAILS_TRY(rails_spmm_planes_interior(c, A, Xp, X->ld, Yp, Y->ld, nc, x_vec2o, c->stream2, &planes_done));
             if (!planes_done) RAILS_TRY(rails_spmm_sweep_interior(c, A, Xp, X->ld, Yp, Y->ld, nc, x_vec2o && y_vec2o, c->stream2, &sweep_done));
             interior_sweep = sweep_done;
             if (!planes_done && !sweep_done) RAILS_TRY(spmm_span(c, A, Xp, X->ld, Xp, X->ld, Yp, Y->ld, nc, x_vec2o, y_vec2o, in, false));
@@ -845,7 +845,7 @@ extern "C" int rails_spmm(rails_ctx *c, rails_csr *A, int trans, const rails_pan
     // structured-grid stencils (complete 7- / 27-point patterns): the plane-sweep kernel (spmm_planes.hip) at every even width
     // -- its plan is one pass over the matrix on the device (a product's worth of time), made by the first product that asks
     if (A->variant == 9 || (A->variant == 0 && nc >= 2 && A->n_ghost == 0 && !A->rect && spmm_env("RAILS_SPMM_PLANES", 1) && rails_csr_is_grid(A))) {
-        const bool al = ((xc0 | yc0) & 1) == 0 && X->ld % 2 == 0 && Y->ld % 2 == 0;
+        const bool al = (xc0 & 1) == 0 && X->ld % 2 == 0; // (16-byte aligned X rows for the LDS-DMA; Y's window may sit on an odd column)
         RAILS_TRY(rails_spmm_planes(c, A, Xp, X->ld, Yp, Y->ld, nc, al, true, &done));
         if (done) {
             c->n_spmm_planes++;

@@ -31,6 +31,7 @@ struct PlanesArgs {
     int npx, npy, nseg, seglen;
     int z_lo, z_hi; // output planes of this launch (the whole grid, or the interior planes of a z-slab whose end planes have ghost columns)
     int wg_per_xcd, nwg;
+    int y_vec; // 1: Y's rows are 16-byte aligned (one store per lane and row), 0: a window on an odd column (two 8-byte stores)
 };
 
 // LPR lanes own a row (two columns each): 64 / LPR rows per wave-instruction.  Narrow panels (the in-loop A * W at Expand size 16 or 32,
@@ -133,8 +134,15 @@ __global__ __launch_bounds__(64 * WX * WY) void k_spmm_planes(const double *__re
     auto store_out = [&](int zo) {
 #pragma unroll
         for (int r = 0; r < RW; ++r)
-            if (xw + r < a.gx && row_line_ok)
-                *reinterpret_cast<double2_t *>(Y + ((int64_t)(zo * a.gy + yw) * a.gx + xw + r) * a.ldy + col0 + 2 * ll) = out[r];
+            if (xw + r < a.gx && row_line_ok) {
+                double *dst = Y + ((int64_t)(zo * a.gy + yw) * a.gx + xw + r) * a.ldy + col0 + 2 * ll;
+                if (a.y_vec)
+                    *reinterpret_cast<double2_t *>(dst) = out[r];
+                else {
+                    dst[0] = out[r].x;
+                    dst[1] = out[r].y;
+                }
+            }
     };
 
     stage(zs - 1, 0);
@@ -307,6 +315,7 @@ static int planes_env(const char *name, int def)
 template <int LPR, int RW, int WX, int WY>
 static int planes_launch(rails_ctx *c, const rails_planes_plan *P, const double *X, int ldx, double *Y, int ldy, int nc, hipStream_t st)
 {
+    const int y_vec = ((((uintptr_t)Y) & 15) == 0 && ldy % 2 == 0) ? 1 : 0;
     constexpr int G = 64 / LPR, NW = WX * WY, PX = RW * WX, PY = WY * G, HXP = (PX + 2 + G - 1) / G * G, NXS = (PY + 2) * (HXP / G);
     constexpr int NCF = (PY * PX * PL_REC * 8 + 1023) / 1024;
     static_assert((2 * NXS + 3 * NCF) * 1024 <= 160 * 1024, "patch too large for the LDS");
@@ -317,6 +326,7 @@ static int planes_launch(rails_ctx *c, const rails_planes_plan *P, const double 
     a.ldx = ldx;
     a.ldy = ldy;
     a.nc = nc;
+    a.y_vec = y_vec;
     a.npx = (P->gx + PX - 1) / PX;
     a.npy = (P->gy + PY - 1) / PY;
     const int nchunks = (nc + 2 * LPR - 1) / (2 * LPR);

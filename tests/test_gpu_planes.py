@@ -58,7 +58,8 @@ def _check(ctx, oracle, A, nc, xoff=0, yoff=0, pad=0):
 @pytest.mark.parametrize("shape,nc,xoff,yoff,pad", [((20, 12, 9), 128, 0, 0, 0), ((17, 13, 7), 128, 2, 4, 3), ((33, 9, 5), 64, 0, 0, 0),
                                                    ((8, 4, 3), 32, 0, 2, 0), ((9, 8, 1), 16, 6, 0, 0), ((5, 3, 40), 2, 0, 0, 0),
                                                    ((24, 21, 6), 256, 0, 0, 0), ((11, 10, 4), 200, 0, 0, 9), ((19, 21, 7), 16, 0, 0, 1),
-                                                   ((23, 37, 5), 32, 2, 0, 0), ((9, 19, 6), 48, 0, 0, 0), ((30, 30, 30), 10, 0, 4, 0)])
+                                                   ((23, 37, 5), 32, 2, 0, 0), ((9, 19, 6), 48, 0, 0, 0), ((30, 30, 30), 10, 0, 4, 0),
+                                                   ((21, 20, 11), 16, 0, 3, 0), ((12, 12, 12), 128, 2, 1, 0), ((15, 14, 9), 32, 0, 5, 1)])
 def test_planes_27_point_is_bitwise_the_rowgather_result_and_matches_the_oracle(ctx, oracle, shape, nc, xoff, yoff, pad):
     """27-point stencil with random coefficients: grids that are not multiples of the patch (partial patches, a single plane, fewer
     planes than a segment), panel windows on even offsets, widths below, at and above one 128-column chunk, padded row strides."""
@@ -100,7 +101,8 @@ def test_planes_declines_what_it_cannot_take(ctx):
     for r in range(m):
         ref[r] = A2[2][rp2[r]:rp2[r + 1]] @ Xh[A2[1][rp2[r]:rp2[r + 1]]]
     assert np.abs(Y.to_host() - ref).max() <= 1e-12
-    # an odd window offset: the complete stencil, but the 16-byte loads of the kernel need even columns
+    # an odd X window offset: the complete stencil, but the 16-byte LDS-DMA pieces of the kernel need even columns (an odd Y offset is
+    # fine: A * W written behind an odd number of basis columns, tested above)
     op = rails_amd.HipOperatorWrapper(ctx, rp, col, val)
     Xh, X, Y, _ = _panels(ctx, m, 64, xoff=1)
     op.set_variant(9)
