@@ -213,15 +213,30 @@ struct GroupRun {
                     }
                 }
             if (first_real < 0) break; // nothing left that has arrived
-            // an idle slot multiplies an X row by zero: the row of its own previous nonzero while that is still in the ring, else
-            // the first row this unit reads anyway
-            for (int t = 0; t < UT; ++t)
+            // An idle slot multiplies an X row by zero.  Which row matters for LDS: a `ds_read_b128` serves 16 lanes (four slots) per
+            // cycle -- lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS), i.e. slots {0, 3, 5, 6},
+            // {1, 2, 4, 7} and the same + 8 -- and the two slots of a group that read the same half of their ring rows first (slot parity:
+            // 0 with 6, 3 with 5, 2 with 4, 1 with 7) collide when their rows have the same parity: one extra cycle for the group
+            // (measured 1.75 cycles per group = 1 + P(either pair collides) = 1 + 3/4).  An idle slot that reads its PARTNER's row asks
+            // for the very same words -- a broadcast, no collision: with 37 % of the slots idle the expectation drops to ~1.36.
+            // (RAILS_SWEEP_IDLE_FILL=0: the row of the slot's own previous nonzero while that is still in the ring, as before.)
+            static const int partner_fill = getenv("RAILS_SWEEP_IDLE_FILL") ? atoi(getenv("RAILS_SWEEP_IDLE_FILL")) : 1;
+            static const int PARTNER[16] = {6, 7, 4, 5, 2, 3, 0, 1, 14, 15, 12, 13, 10, 11, 8, 9};
+            for (int t = 0; t < UT; ++t) {
+                bool real[SLOTS];
+                for (int s = 0; s < SLOTS; ++s) real[s] = o[t][s] >= 0;
                 for (int s = 0; s < SLOTS; ++s) {
-                    if (o[t][s] >= 0)
+                    if (real[s]) {
                         last_pos[s] = o[t][s];
+                        continue;
+                    }
+                    const int q = partner_fill == 2 ? (s ^ 2) : PARTNER[s]; // (2: experiment -- four consecutive slots served together)
+                    if (partner_fill && (real[q] || q < s))
+                        o[t][s] = o[t][q]; // the partner's row (its own if it has work, else what it was given: q < s is assigned already)
                     else
                         o[t][s] = (last_pos[s] >= 0 && last_pos[s] >= lo) ? last_pos[s] : first_real;
                 }
+            }
             for (int t = 0; t < UT; ++t) stream->emit(v[t], o[t], ring);
             out.step.push_back(k);
             out.flags.push_back(0);
