@@ -217,11 +217,11 @@ int rails_gram(rails_ctx *ctx, const rails_panel *X, int xc0, int a, const rails
 int rails_panel_gemm(rails_ctx *ctx, double alpha, const rails_panel *X, int xc0, int k, const double *C_host,
                      int ldc, int r, double beta, rails_panel *Y, int yc0);
 
-/* The platform's BLAS (rocBLAS, resolved with dlopen) for the one plain wide GEMM of the library: rails_panel_gemm_wide with
- * k, r >= 64 (the basis rotation of the coordinate-space back end, compute-bound: 44 instead of 30 TFLOP/s).  Creating its handle takes
- * ~0.3 s in a warm process, seconds in a cold one (once per process, for the calling context's device): an application that is going
- * to solve many systems calls this when it sets up; nothing in the library does by itself.  Until then --
- * rails_ctx_library_gemm_ready -- or without the library (or with RAILS_WIDE_GEMM=own) the hand-written kernel does the work. */
+/* Opt-in since round 3 (the library's own one-pass MFMA kernel, k_panel_gemm_wide, is the default and the faster one: 49 against 43-46
+ * TFLOP/s at k = 324, r = 268): with RAILS_WIDE_GEMM=rocblas in the environment this call creates a rocBLAS handle (resolved with dlopen;
+ * ~0.3 s in a warm process, seconds in a cold one, once per process, for the calling context's device, on the CALLING thread) and
+ * rails_panel_gemm_wide with k, r >= 64 goes through rocblas_dgemm from then on (rails_ctx_library_gemm_ready).  Without the variable
+ * the call does nothing. */
 int rails_ctx_enable_library_gemm(rails_ctx *ctx);
 int rails_ctx_library_gemm_ready(const rails_ctx *ctx);
 

@@ -95,7 +95,7 @@ class Context:
         return json.loads(buf.value.decode())
 
     def enable_library_gemm(self):
-        """set up the platform's BLAS for the basis rotation of restarts now (0.3 s, once per process) rather than at the second restart"""
+        """opt-in (with RAILS_WIDE_GEMM=rocblas in the environment): the basis rotation of restarts through rocBLAS instead of the library's own kernel"""
         check(self.lib.rails_ctx_enable_library_gemm(self.h), "rails_ctx_enable_library_gemm")
 
     def set_meter(self, on=True):
