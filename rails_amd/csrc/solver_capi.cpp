@@ -217,10 +217,10 @@ static int solve_in_coordinates(rails_solver *s)
     s->sub_trips = solver.trips();
     s->sub_hist = solver.residual_history();
     s->sub_profile = solver.profile();
-    char buf[1024];
-    snprintf(buf, sizeof(buf), "{\"dim\": %d, \"absorb\": %ld, \"absorb_columns\": %ld, \"one_by_one\": %ld, \"dropped\": %ld, \"compress\": %ld, \"materialise\": %ld, \"prefetched_random\": %ld, \"second_rounds\": %ld, \"delicate_blocks\": %ld, \"reprojected_blocks\": %ld, \"overlapped_blocks\": %ld, \"replaced_columns\": %ld, \"seconds\": {\"materialise\": %.4f, \"absorb\": %.4f, \"compress_qr\": %.4f, \"compress_rotate\": %.4f, "
+    char buf[1536];
+    snprintf(buf, sizeof(buf), "{\"dim\": %d, \"absorb\": %ld, \"absorb_columns\": %ld, \"one_by_one\": %ld, \"dropped\": %ld, \"compress\": %ld, \"materialise\": %ld, \"prefetched_random\": %ld, \"second_rounds\": %ld, \"delicate_blocks\": %ld, \"reprojected_blocks\": %ld, \"overlapped_blocks\": %ld, \"replaced_columns\": %ld, \"verified\": %d, \"verify_representation\": %.3e, \"verify_orthonormality\": %.3e, \"seconds\": {\"materialise\": %.4f, \"absorb\": %.4f, \"compress_qr\": %.4f, \"compress_rotate\": %.4f, "
              "\"compress_coefficients\": %.4f}}",
-             basis->dim, basis->n_absorb, basis->n_absorb_cols, basis->n_single, basis->n_dropped, basis->n_compress, basis->n_materialise, basis->n_prefetched, basis->n_second_round, basis->n_delicate, basis->n_reprojected, basis->n_overlapped, basis->n_replaced,
+             basis->dim, basis->n_absorb, basis->n_absorb_cols, basis->n_single, basis->n_dropped, basis->n_compress, basis->n_materialise, basis->n_prefetched, basis->n_second_round, basis->n_delicate, basis->n_reprojected, basis->n_overlapped, basis->n_replaced, basis->verify ? 1 : 0, basis->verify_repr, basis->verify_orth,
              basis->t_materialise, basis->t_absorb, basis->t_qr, basis->t_rotate, basis->t_recoef);
     s->sub_stats = buf;
     if (basis->failed) {

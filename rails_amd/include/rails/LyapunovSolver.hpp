@@ -25,6 +25,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <iostream>
 #include <map>
@@ -545,6 +547,15 @@ private:
         void reduce()
         {
             ScopedTimer t(&s_.sections_, "dense_solve");
+            if (const char *dump = getenv("RAILS_DEBUG_DUMP_PROJECTED")) { // diagnostics: the projected matrices of this trip, as text
+                if (FILE *f = fopen(dump, "a")) {
+                    const int k = a_.M();
+                    fprintf(f, "%d\n", k);
+                    for (int j = 0; j < k; ++j)
+                        for (int i = 0; i < k; ++i) fprintf(f, "%.17g %.17g\n", (double)a_(i, j), (double)b_(i, j));
+                    fclose(f);
+                }
+            }
             if (s_.mass_ && !s_.ortho_m_)
                 s_.generalized_dense_solve(a_, b_, m_, T_);
             else

@@ -204,7 +204,44 @@ public:
     // The w columns X sitting in P's tail [dim, dim+w) are expressed in the basis: the part of X outside span(P) becomes new
     // orthonormal basis columns, coef (row_cap x w, zero-initialised by the caller, ld = row_cap) receives the coordinates of X in
     // the extended basis.  Block CGS2 against P, CholQR2 inside the block; the representation is X = P_old (C1 + C2) + Q (R2 R1).
+    // RAILS_SUBSPACE_VERIFY=1 (diagnostics, tests): every synchronous block is checked after the fact -- the largest column of
+    // X - P * coef relative to the column of X, and the largest entry of P'P - I, are kept in verify_repr / verify_orth.
+    bool verify = getenv("RAILS_SUBSPACE_VERIFY") != nullptr;
+    double verify_repr = 0.0, verify_orth = 0.0;
+    HipMultiVectorWrapper Xv;
     bool absorb_tail(int w, double *coef)
+    {
+        if (!verify || w <= 0) return absorb_tail_impl(w, coef);
+        if (!resolve_pending()) return false;
+        if (Xv.N() < 0 || Xv.capacity() < w) Xv = HipMultiVectorWrapper(m_local, std::max(w, 64), ctx);
+        Xv.resize(w);
+        if (!hip_ok(rails_panel_copy(ctx, P.panel(), dim, w, Xv.panel(), 0), "rails_panel_copy")) return fail();
+        std::vector<double> n0(w * w), n1(w * w);
+        if (!hip_ok(rails_gram(ctx, Xv.panel(), 0, w, Xv.panel(), 0, w, n0.data(), w), "rails_gram")) return fail();
+        const int dim_before = dim;
+        const bool ok = absorb_tail_impl(w, coef);
+        if (!ok || pending.active) return ok;
+        if (!hip_ok(rails_panel_gemm(ctx, -1.0, P.panel(), 0, dim, coef, row_cap, w, 1.0, Xv.panel(), 0), "rails_panel_gemm")) return fail();
+        if (!hip_ok(rails_gram(ctx, Xv.panel(), 0, w, Xv.panel(), 0, w, n1.data(), w), "rails_gram")) return fail();
+        double worst = 0.0;
+        for (int j = 0; j < w; ++j)
+            if (n0[j + (size_t)j * w] > 0.0) worst = std::max(worst, std::sqrt(n1[j + (size_t)j * w] / n0[j + (size_t)j * w]));
+        std::vector<double> PP((size_t)dim * dim);
+        if (!hip_ok(rails_gram(ctx, P.panel(), 0, dim, P.panel(), 0, dim, PP.data(), dim), "rails_gram")) return fail();
+        double orth = 0.0, against_old = 0.0;
+        int wi = -1, wj = -1;
+        for (int j = 0; j < dim; ++j)
+            for (int i = 0; i < dim; ++i) {
+                const double e = std::fabs(PP[i + (size_t)j * dim] - (i == j ? 1.0 : 0.0));
+                if (e > orth) { orth = e; wi = i; wj = j; }
+                if (j >= dim_before && i < dim_before) against_old = std::max(against_old, e);
+            }
+        if (trace) std::cerr << "absorb verified: dim " << dim_before << " -> " << dim << " w " << w << ": |X - P c| / |X| <= " << worst << ", |P'P - I| = " << orth << " at (" << wi << ", " << wj << "), new against old columns " << against_old << std::endl;
+        verify_repr = std::max(verify_repr, worst);
+        verify_orth = std::max(verify_orth, orth);
+        return true;
+    }
+    bool absorb_tail_impl(int w, double *coef)
     {
         if (!resolve_pending()) return false;
         n_absorb++;
@@ -296,8 +333,10 @@ public:
         for (int j = 0; j < w; ++j) {
             if (G[j + (size_t)j * w] > 1e-26 * G0[j + (size_t)j * w] && G[j + (size_t)j * w] > 0.0)
                 keep.push_back(j);
-            else
+            else {
                 n_dropped++;
+                if (trace) std::cerr << "absorb: column " << j << " dropped after the projections: " << G[j + (size_t)j * w] << " left of " << G0[j + (size_t)j * w] << std::endl;
+            }
         }
         // A column of which less than 1e-4 of its length survived the projections may be nothing but their rounding error --
         // normalised, such a "direction" would not be orthogonal to P (error ~ eps / survival) and poison the basis; this happens
@@ -318,11 +357,14 @@ public:
             if (!hip_ok(rails_gram(ctx, pp, dim, w, pp, dim, w, G.data(), w), "rails_gram")) return fail();
             std::vector<int> survivors;
             for (int j : keep) {
-                if (G[j + (size_t)j * w] > 0.25) {
-                    for (int i = 0; i < dim; ++i) coef[i + (size_t)j * ld] += colscale[j] * CG[i + (size_t)j * dim];
+                // (what the third projection took out belongs to the column whether or not the rest of it is kept)
+                for (int i = 0; i < dim; ++i) coef[i + (size_t)j * ld] += colscale[j] * CG[i + (size_t)j * dim];
+                if (G[j + (size_t)j * w] > 0.25)
                     survivors.push_back(j);
-                } else
+                else {
                     n_dropped++;
+                    if (trace) std::cerr << "absorb: delicate column " << j << " dropped: " << G[j + (size_t)j * w] << " of its unit length left (it was " << colscale[j] << " long)" << std::endl;
+                }
             }
             keep.swap(survivors);
         }
@@ -688,15 +730,22 @@ private:
             if (src != dst && !hip_ok(rails_panel_copy(ctx, pp, src, 1, pp, dst), "rails_panel_copy")) return fail();
             double g0 = 0.0, g = 0.0;
             if (!hip_ok(rails_gram(ctx, pp, dst, 1, pp, dst, 1, &g0, 1), "rails_gram")) return fail();
-            for (int round = 0; round < 2 && accepted > 0; ++round) { // against the columns accepted from this block
-                std::vector<double> c(accepted);
-                if (!hip_ok(rails_gram(ctx, pp, base, accepted, pp, dst, 1, c.data(), accepted), "rails_gram")) return fail();
-                if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, base, accepted, c.data(), accepted, 1, 1.0, pp, dst), "rails_panel_gemm")) return fail();
-                for (int a = 0; a < accepted; ++a) coef[(base + a) + (size_t)j * ld] += colscale[j] * c[a];
+            // Two rounds against the WHOLE basis so far, not only against the columns accepted from this block: a column that keeps a
+            // fraction f of its length here inherits the accepted columns' defects against the old basis magnified by 1 / f, and in a
+            // chain of nearly dependent columns (the first residual directions of a run all lie close to span(B)) that compounds
+            // geometrically -- measured on BASELINE configs[1]: P'P - I of 2e-14, 2e-12, 1e-10, 4e-9, 1e-8 along one block of 25
+            // columns, 3e-5 two trips later, and projected matrices V'AV off by the same.
+            for (int round = 0; round < 2 && accepted > 0; ++round) {
+                const int nb = base + accepted;
+                std::vector<double> c(nb);
+                if (!hip_ok(rails_gram(ctx, pp, 0, nb, pp, dst, 1, c.data(), nb), "rails_gram")) return fail();
+                if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, nb, c.data(), nb, 1, 1.0, pp, dst), "rails_panel_gemm")) return fail();
+                for (int a = 0; a < nb; ++a) coef[a + (size_t)j * ld] += colscale[j] * c[a];
             }
             if (!hip_ok(rails_gram(ctx, pp, dst, 1, pp, dst, 1, &g, 1), "rails_gram")) return fail();
             if (!(g > 1e-24 * g0) || !(g > 0.0)) {
                 n_dropped++;
+                if (trace) std::cerr << "absorb one by one: column " << j << " dropped: " << g << " left of " << g0 << " (scale " << colscale[j] << ")" << std::endl;
                 continue;
             }
             const double nrm = std::sqrt(g);
@@ -711,15 +760,27 @@ private:
                 if (!hip_ok(rails_gram(ctx, pp, 0, nb, pp, dst, 1, c.data(), nb), "rails_gram")) return fail();
                 if (!hip_ok(rails_panel_gemm(ctx, -1.0, pp, 0, nb, c.data(), nb, 1, 1.0, pp, dst), "rails_panel_gemm")) return fail();
                 if (!hip_ok(rails_gram(ctx, pp, dst, 1, pp, dst, 1, &n2, 1), "rails_gram")) return fail();
+                // what the projection took out belongs to the column whether or not the rest of it is kept
+                for (int a = 0; a < nb; ++a) coef[a + (size_t)j * ld] += colscale[j] * nrm * c[a];
                 if (!(n2 > 0.25)) {
                     n_dropped++;
+                    if (trace) std::cerr << "absorb one by one: column " << j << " dropped after the check against the whole basis: " << n2 << " of its unit length left (it was " << colscale[j] * nrm << " long)" << std::endl;
                     continue;
                 }
-                for (int a = 0; a < nb; ++a) coef[a + (size_t)j * ld] += colscale[j] * nrm * c[a];
                 if (!hip_ok(rails_panel_scale(ctx, pp, dst, 1, 1.0 / std::sqrt(n2)), "rails_panel_scale")) return fail();
                 last = nrm * std::sqrt(n2);
             }
             coef[(base + accepted) + (size_t)j * ld] = colscale[j] * last;
+            if (trace) std::cerr << "absorb one by one: column " << j << " -> basis column " << base + accepted << ": " << g << " left of " << g0 << " (scale " << colscale[j] << ")" << std::endl;
+            if (verify && trace && base + accepted > 0) {
+                std::vector<double> c(base + accepted);
+                rails_gram(ctx, pp, 0, base + accepted, pp, dst, 1, c.data(), base + accepted);
+                double e = 0.0;
+                int at = -1;
+                for (int a = 0; a < base + accepted; ++a)
+                    if (std::fabs(c[a]) > e) { e = std::fabs(c[a]); at = a; }
+                std::cerr << "    against the basis so far: " << e << " at column " << at << std::endl;
+            }
             accepted++;
         }
         dim = base + accepted;
