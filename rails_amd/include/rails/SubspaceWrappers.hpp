@@ -690,6 +690,15 @@ public:
                     for (int a = 0; a < w; ++a) cj[d0 + a] = bn[a];
                 }
             }
+        if (verify && !failed) { // (RAILS_SUBSPACE_VERIFY: the basis with the block the device has just finished)
+            std::vector<double> PP((size_t)dim * dim);
+            if (!hip_ok(rails_gram(ctx, P.panel(), 0, dim, P.panel(), 0, dim, PP.data(), dim), "rails_gram")) return fail();
+            double orth = 0.0;
+            for (int j = 0; j < dim; ++j)
+                for (int i = 0; i < dim; ++i) orth = std::max(orth, std::fabs(PP[i + (size_t)j * dim] - (i == j ? 1.0 : 0.0)));
+            if (trace) std::cerr << "absorb (overlapped) verified: dim " << d0 << " -> " << dim << ": |P'P - I| = " << orth << std::endl;
+            verify_orth = std::max(verify_orth, orth);
+        }
         return !failed;
     }
 

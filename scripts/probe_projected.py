@@ -16,7 +16,7 @@ def read(path):
     toks = open(path).read().split()
     k = int(toks[0]); d = np.array(toks[1:1 + 2 * k * k], dtype=float).reshape(k * k, 2)
     return d[:, 0].reshape(k, k).T, d[:, 1].reshape(k, k).T
-for j in (3, 4, 6, 9):
+for j in (3, 4, 6, 9):  # trips of the oracle run whose V is handed over
     head = orc.solve(A, B, orc.params({**params, "Maximum iterations": j, "rng_mode": 1, "seed": seed}))
     V0 = np.ascontiguousarray(head["V"])
     one = {**params, "Restart from solution": 1, "Maximum iterations": 1}
