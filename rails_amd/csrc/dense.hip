@@ -130,7 +130,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 // of a block take four ADJACENT 64-column strips of X for the SAME rows, so a block reads whole 2 KiB row segments (the row-split
 // form above reads 512 B per row and block; measured 3.0 -> see profiles/r01_kernels.md) and Y's few columns once; every wave owns
 // its output tiles, so there is no cross-wave reduction.  Two 4-row steps are in flight per wave.
-template <int TI, int TJ>
+// NE columns of Y beyond 16 * TJ (the prefetched random vector that rides at the end of an A*W block: b = 17) are done with plain
+// multiply-adds on the values the lanes hold anyway: a second MFMA column tile for ONE column doubles the matrix work, and the pass
+// took a third longer for it (0.81 against 0.61 ms at 369 x 17 / 369 x 16, 1M rows).  A lane sums its own rows (r + kk, r + 4 + kk, ...) of
+// its own column; the four row classes are added at the end (kk = 0 + 1, + 2, + 3: a fixed order).
+template <int TI, int TJ, int NE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_gram_cols(const double *__restrict__ X, int ldx, int a,
                                                                                              const double *__restrict__ Y, int ldy, int b, int64_t m,
                                                                                              int64_t rows_per_slab, double *__restrict__ partial)
@@ -149,13 +153,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    double acce[TI][NE > 0 ? NE : 1];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < (NE > 0 ? NE : 1); ++q) acce[i][q] = 0.0;
     bool xok[TI], yok[TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i) xok[i] = (xcol0 + 16 * i + li) < a;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) yok[j] = (16 * j + li) < b;
 
-    auto fetch = [&](int64_t r, double *xa, double *yb) {
+    auto fetch = [&](int64_t r, double *xa, double *yb, double *ye) {
         const int64_t row = r + kk;
         const bool rok = row < r_end;
         const double *xr = X + row * ldx + xcol0 + li;
@@ -164,21 +173,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         for (int i = 0; i < TI; ++i) xa[i] = (rok && xok[i]) ? xr[16 * i] : 0.0;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) yb[j] = (rok && yok[j]) ? yr[16 * j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NE; ++q) ye[q] = (rok && 16 * TJ + q < b) ? Y[row * ldy + 16 * TJ + q] : 0.0; // (one address per row: a broadcast)
     };
-    double xa[TI], ya[TJ], xb[TI], yb[TJ];
-    fetch(r_begin, xa, ya);
-    fetch(r_begin + 4, xb, yb);
+    auto work = [&](const double *xa, const double *yb, const double *ye) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = mfma_f64(xa[i], yb[j], acc[i][j]);
+#pragma unroll
+            for (int q = 0; q < NE; ++q) acce[i][q] += xa[i] * ye[q];
+        }
+    };
+    double xa[TI], ya[TJ], xb[TI], yb[TJ], ea[NE > 0 ? NE : 1], eb[NE > 0 ? NE : 1];
+    fetch(r_begin, xa, ya, ea);
+    fetch(r_begin + 4, xb, yb, eb);
     for (int64_t r = r_begin; r < r_end; r += 8) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[i][j] = mfma_f64(xa[i], ya[j], acc[i][j]);
-        fetch(r + 8, xa, ya); // rows past the slab come back as zeros
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[i][j] = mfma_f64(xb[i], yb[j], acc[i][j]);
-        fetch(r + 12, xb, yb);
+        work(xa, ya, ea);
+        fetch(r + 8, xa, ya, ea); // rows past the slab come back as zeros
+        work(xb, yb, eb);
+        fetch(r + 12, xb, yb, eb);
     }
     double *P = partial + (int64_t)blockIdx.x * a * b;
 #pragma unroll
@@ -191,6 +205,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 int cj = 16 * j + li;                 // D col  -> Y column
                 if (ci < a && cj < b) P[ci + (int64_t)cj * a] = acc[i][j][v];
             }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const double t0 = acce[i][q];
+            const double t1 = __shfl(t0, li + 16, 64), t2 = __shfl(t0, li + 32, 64), t3 = __shfl(t0, li + 48, 64);
+            const int ci = xcol0 + 16 * i + li;
+            if (kk == 0 && ci < a && 16 * TJ + q < b) P[ci + (int64_t)(16 * TJ + q) * a] = ((t0 + t1) + t2) + t3;
+        }
 }
 
 // out[e] = sum_t partial[t][e] in a fixed order: 16 interleaved strands per element, then the strands 0..15
@@ -448,30 +471,40 @@ int rails_gram_dev(rails_ctx *c, const double *X, int ldx, const double *Y, int 
         if (cols_form) {
             // tiles of 16 X-columns per wave: the choice that leaves the fewest idle tile slots in blocks of four waves
             const int ntiles = (a + 15) / 16;
+            // b = 17: one MFMA column tile and the 17th column on the vector unit (see k_gram_cols)
+            static const int extra_env = getenv("RAILS_GRAM_EXTRA_COLUMN") ? atoi(getenv("RAILS_GRAM_EXTRA_COLUMN")) : 1;
+            const bool extra = extra_env && b == 17;
             const int cand2[3] = {3, 4, 5}, cand1[3] = {4, 6, 8};
-            const int *cand = b <= 16 ? cand1 : cand2;
+            const int *cand = (b <= 16 || extra) ? cand1 : cand2;
             int best = cand[1], best_cost = 1 << 30;
             for (int q = 0; q < 3; ++q) {
                 int ti = cand[q], strips = (ntiles + ti - 1) / ti, cost = (strips + 3) / 4 * 4 * ti;
                 if (cost < best_cost) best = ti, best_cost = cost;
             }
             const dim3 grid((unsigned)nslab, (unsigned)(((ntiles + best - 1) / best + 3) / 4));
-#define RAILS_GRAM_COLS_CASE(TI, TJ)                                                                                                     \
-    RAILS_LAUNCH((k_gram_cols<TI, TJ>), grid, dim3(256), 0, c->stream, X, ldx, a, Y, ldy, b, m, rps, c->ws)
-            if (b <= 16) {
+#define RAILS_GRAM_COLS_CASE(TI, TJ, NE)                                                                                                 \
+    RAILS_LAUNCH((k_gram_cols<TI, TJ, NE>), grid, dim3(256), 0, c->stream, X, ldx, a, Y, ldy, b, m, rps, c->ws)
+            if (extra) {
                 if (best == 4)
-                    RAILS_GRAM_COLS_CASE(4, 1);
+                    RAILS_GRAM_COLS_CASE(4, 1, 1);
                 else if (best == 6)
-                    RAILS_GRAM_COLS_CASE(6, 1);
+                    RAILS_GRAM_COLS_CASE(6, 1, 1);
                 else
-                    RAILS_GRAM_COLS_CASE(8, 1);
+                    RAILS_GRAM_COLS_CASE(8, 1, 1);
+            } else if (b <= 16) {
+                if (best == 4)
+                    RAILS_GRAM_COLS_CASE(4, 1, 0);
+                else if (best == 6)
+                    RAILS_GRAM_COLS_CASE(6, 1, 0);
+                else
+                    RAILS_GRAM_COLS_CASE(8, 1, 0);
             } else {
                 if (best == 3)
-                    RAILS_GRAM_COLS_CASE(3, 2);
+                    RAILS_GRAM_COLS_CASE(3, 2, 0);
                 else if (best == 4)
-                    RAILS_GRAM_COLS_CASE(4, 2);
+                    RAILS_GRAM_COLS_CASE(4, 2, 0);
                 else
-                    RAILS_GRAM_COLS_CASE(5, 2);
+                    RAILS_GRAM_COLS_CASE(5, 2, 0);
             }
 #undef RAILS_GRAM_COLS_CASE
         } else if (b <= 16)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--m", type=int, default=1000000)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--k", type=int, default=352)
+    ap.add_argument("--skip-rotation", action="store_true", help="only the block Gram-Schmidt passes")
     args = ap.parse_args()
     import rails_amd
     from rails_amd._lib import check
@@ -58,24 +59,25 @@ def main():
     P1 = panel(k, 776)
     P2 = MV(ctx, m=m, n=r, capacity=400)
     Q = np.asfortranarray(np.linalg.qr(rng.standard_normal((k, r)))[0])
-    timed("panel_gemm_wide k=%d r=%d (restart rotation P2 = P Q)" % (k, r),
-          lambda: check(lib.rails_panel_gemm_wide(ctx.h, 1.0, P1.panel.h, 0, k, _p(Q), k, r, 0.0, P2.panel.h, 0), "wide"), (k + r) * m * S, 2.0 * m * k * r)
-    got = P2.to_host()[rows]
-    want = P1.to_host()[rows] @ Q
-    print(json.dumps({"check": "rotation", "max_abs_err": float(np.abs(got - want).max()), "scale": float(np.abs(want).max())}), flush=True)
-    assert np.abs(got - want).max() <= 1e-12 * k
-    for kk, rr in ((200, 128), (430, 290), (520, 400)):
-        Pk = panel(kk, 776) if kk > k else P1
-        Pr = MV(ctx, m=m, n=rr, capacity=400)
-        Qk = np.asfortranarray(np.linalg.qr(rng.standard_normal((kk, rr)))[0])
-        timed("panel_gemm_wide k=%d r=%d" % (kk, rr),
-              lambda: check(lib.rails_panel_gemm_wide(ctx.h, 1.0, Pk.panel.h, 0, kk, _p(Qk), kk, rr, 0.0, Pr.panel.h, 0), "wide"), (kk + rr) * m * S, 2.0 * m * kk * rr)
-        got = Pr.to_host()[rows]
-        want = Pk.to_host()[rows, :kk] @ Qk
-        assert np.abs(got - want).max() <= 1e-12 * kk, (kk, rr, np.abs(got - want).max())
-        del Pr
-        if kk > k:
-            del Pk
+    if not args.skip_rotation:
+        timed("panel_gemm_wide k=%d r=%d (restart rotation P2 = P Q)" % (k, r),
+              lambda: check(lib.rails_panel_gemm_wide(ctx.h, 1.0, P1.panel.h, 0, k, _p(Q), k, r, 0.0, P2.panel.h, 0), "wide"), (k + r) * m * S, 2.0 * m * k * r)
+        got = P2.to_host()[rows]
+        want = P1.to_host()[rows] @ Q
+        print(json.dumps({"check": "rotation", "max_abs_err": float(np.abs(got - want).max()), "scale": float(np.abs(want).max())}), flush=True)
+        assert np.abs(got - want).max() <= 1e-12 * k
+        for kk, rr in ((200, 128), (430, 290), (520, 400)):
+            Pk = panel(kk, 776) if kk > k else P1
+            Pr = MV(ctx, m=m, n=rr, capacity=400)
+            Qk = np.asfortranarray(np.linalg.qr(rng.standard_normal((kk, rr)))[0])
+            timed("panel_gemm_wide k=%d r=%d" % (kk, rr),
+                  lambda: check(lib.rails_panel_gemm_wide(ctx.h, 1.0, Pk.panel.h, 0, kk, _p(Qk), kk, rr, 0.0, Pr.panel.h, 0), "wide"), (kk + rr) * m * S, 2.0 * m * kk * rr)
+            got = Pr.to_host()[rows]
+            want = Pk.to_host()[rows, :kk] @ Qk
+            assert np.abs(got - want).max() <= 1e-12 * kk, (kk, rr, np.abs(got - want).max())
+            del Pr
+            if kk > k:
+                del Pk
     del P2
     # ---- the block Gram-Schmidt passes of a trip ------------------------------------------------------------------
     k = args.k
@@ -84,6 +86,9 @@ def main():
     out = np.zeros((k + 17, 17), order="F")
     timed("gram [P | X]' X  %d x 17 (first projection round)" % (k + 17),
           lambda: lib.rails_gram(ctx.h, Pb.panel.h, 0, k + 17, Pb.panel.h, k, 17, _p(out), k + 17), (k + 17) * m * S, 2.0 * m * (k + 17) * 17)
+    out16 = np.zeros((k + 17, 16), order="F")
+    timed("gram [P | X]' X  %d x 16 (the same without the 17th column)" % (k + 17),
+          lambda: lib.rails_gram(ctx.h, Pb.panel.h, 0, k + 17, Pb.panel.h, k, 16, _p(out16), k + 17), (k + 17) * m * S, 2.0 * m * (k + 17) * 16)
     Wc = np.asfortranarray(rng.uniform(-1, 1, (k, 16)) * 1e-3)
     Wp = MV(ctx, m=m, n=16, capacity=16)
     timed("panel_gemm k=%d r=16 (materialise W = P Wc)" % k,
