@@ -54,24 +54,34 @@ class SchurOperator:
         self.dA12t, self.dA21t = rect(self.A12.T), rect(self.A21.T)
         self.applies = 0  # matrix-vector products, as SchurOperator::GetMVPs counts them
         self.host_bytes = 0  # bytes that crossed PCIe in _apply (diagnostics)
+        self._ws = {}
         self.op = HipOperatorWrapper.from_callback(ctx, self.m2, self._apply)
 
+    def _workspace(self, nc):
+        """the three panels a product needs (A12 X and the solution of the A11 system on set 1, A21 Z on set 2), kept per width: a product
+        allocates nothing after the first of its width"""
+        ws = self._ws.get(nc)
+        if ws is None:
+            ws = (HipMultiVectorWrapper(self.ctx, self.m1, nc, capacity=max(1, nc)), HipMultiVectorWrapper(self.ctx, self.m1, nc, capacity=max(1, nc)),
+                  HipMultiVectorWrapper(self.ctx, self.m2, nc, capacity=max(1, nc)))
+            self._ws[nc] = ws
+        return ws
+
     def _apply(self, trans, X, Y):
-        """Y = S X (or S' X): three device SpMMs; the LU solve with A11 on the host, on an m1 x nc block"""
+        """Y = S X (or S' X): three device SpMMs; the LU solve with A11 on the host, on an m1 x nc block.  The only synchronisation is
+        the one the host solve needs (the block has to have arrived); everything after it is queued and returns."""
         self.applies += X.n
         lib = self.ctx.lib
+        W, Zd, tmp = self._workspace(X.n)
         check(lib.rails_spmm(self.ctx.h, self.A22.h.h, 1 if trans else 0, X.panel.h, X.c0, X.n, Y.panel.h, Y.c0), "rails_spmm")
         first, second = (self.dA12, self.dA21) if not trans else (self.dA21t, self.dA12t)  # S' = A22' - A12' A11^-T A21'
-        W = HipMultiVectorWrapper(self.ctx, self.m1, X.n, capacity=max(1, X.n))
         check(lib.rails_spmm(self.ctx.h, first.h.h, 0, X.panel.h, X.c0, X.n, W.panel.h, 0), "rails_spmm")
         Wh = W.to_host()
         Z = self.lu.solve(np.ascontiguousarray(Wh), trans="T" if trans else "N")
         self.host_bytes += 2 * Wh.nbytes
-        Zd = HipMultiVectorWrapper(self.ctx, data=np.asfortranarray(Z.reshape(self.m1, X.n)))
-        tmp = HipMultiVectorWrapper(self.ctx, self.m2, X.n, capacity=max(1, X.n))
+        Zd.from_host(np.asfortranarray(Z.reshape(self.m1, X.n)))
         check(lib.rails_spmm(self.ctx.h, second.h.h, 0, Zd.panel.h, 0, X.n, tmp.panel.h, 0), "rails_spmm")
         check(lib.rails_panel_axpy(self.ctx.h, -1.0, tmp.panel.h, 0, X.n, Y.panel.h, Y.c0), "rails_panel_axpy")
-        self.ctx.sync()  # the temporaries are released when this returns
         return 0
 
     def restrict(self, B):
