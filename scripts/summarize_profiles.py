@@ -82,7 +82,7 @@ def main():
             if n_here >= best.get(key, (0, 0))[0]:
                 fa2 = fetch.get(k, {}).get("FETCH_SIZE", [0.0])
                 wa2 = write.get(k, {}).get("WRITE_SIZE", [0.0])
-                best[key] = (n_here, (2 * sum(fa2) / len(fa2) + sum(wa2) / len(wa2)) * 1024)
+                best[key] = (n_here, (2 * sum(fa2) / len(fa2) + sum(wa2) / len(wa2)) * 1024, k)
     lines.append("")
     traffic = {k: v[1] for k, v in best.items()}
     # the kernel's average duration in the stats pass of the same build: bench.py compares it with what it measures live and says so in
@@ -90,7 +90,11 @@ def main():
     if stats:
         for key in list(traffic):
             kname = key.split(":")[0]
-            durs = [(int(r["Calls"]), float(r["AverageNs"]) / 1e3) for r in rows if short(r["Name"]).split("<")[0] == kname]
+            # the instantiation the PMC pass saw (template arguments and all: a kernel family has other widths in the same run); the
+            # family's most-called member only when the stats pass does not have that one
+            durs = [(int(r["Calls"]), float(r["AverageNs"]) / 1e3) for r in rows if short(r["Name"]) == best[key][2]]
+            if not durs:
+                durs = [(int(r["Calls"]), float(r["AverageNs"]) / 1e3) for r in rows if short(r["Name"]).split("<")[0] == kname]
             if durs:
                 traffic[key + ":kernel_us"] = max(durs)[1]
     json.dump(traffic, open(os.path.join(dst, "traffic_%s_%s.json" % (tag, pattern)), "w"), indent=1)
