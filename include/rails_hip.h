@@ -172,6 +172,24 @@ const char *rails_csr_last_kernel(const rails_csr *A);
  * nnz / (slots x trips), dinfo[1] = X rows staged per matrix row and column chunk.  rails_sweep_plan_array lends the
  * arrays of the plan (which = 0 part_row0 i64, 1 sweep0 i64, 2 nsteps i32, 3 hdr_off i64, 4 batch_off i64, 5 flush_off i64,
  * 6 codes u32, 7 vals f64, 8 offs u16, 9 flush_rows i32); they live until rails_sweep_plan_destroy. */
+/* ---- sparse triangular solves on device panels (rails_amd/csrc/sptrsv.hip) -----------------------------------------------------------
+ * The A11 systems of the Schur-complement operator: the reference factorises A11 with Amesos KLU and solves on the host inside every
+ * product (src/SchurOperator.cpp:171-176 set-up, :181-214 Apply); here a host factorisation's L and U are applied on the device by level
+ * scheduling, so that the blocks of a product stay where the SpMM kernels left them.  A triangle comes in CSR (columns of a row in any
+ * order); `lower` != 0: entries on or below the diagonal; `unit_diag` != 0: ones on the diagonal, not stored. */
+typedef struct rails_sptrsv rails_sptrsv;
+int rails_sptrsv_create(rails_ctx *ctx, int64_t n, const int64_t *rowptr, const int32_t *col, const double *val, int lower, int unit_diag,
+                        rails_sptrsv **out);
+void rails_sptrsv_destroy(rails_sptrsv *T);
+int64_t rails_sptrsv_levels(const rails_sptrsv *T); /* number of levels of the dependency graph (diagnostics) */
+/* X[:, c0:c0+nc] <- T^-1 X[:, c0:c0+nc] in place, queued on the context's stream */
+int rails_sptrsv_solve(rails_ctx *ctx, const rails_sptrsv *T, rails_panel *X, int c0, int nc);
+/* row permutations of a factorisation: Y row i <- X row perm[i] (scatter == 0) or Y row perm[i] <- X row i (scatter != 0); perm lives in
+ * device memory (rails_index_upload / rails_index_free) */
+int rails_panel_permute_rows(rails_ctx *ctx, const rails_panel *X, int xc0, int nc, const int32_t *perm_dev, int scatter, rails_panel *Y, int yc0);
+int rails_index_upload(rails_ctx *ctx, const int32_t *host, int64_t n, int32_t **out_dev);
+void rails_index_free(rails_ctx *ctx, int32_t *dev);
+
 typedef struct rails_sweep_plan rails_sweep_plan;
 int rails_sweep_plan_create(int64_t m, int64_t ncols, const int64_t *rowptr, const int32_t *col, const double *val,
                             const int *params, rails_sweep_plan **out);

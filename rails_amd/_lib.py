@@ -76,6 +76,13 @@ SIGNATURES = {
     "rails_panel_scale": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double]),
     "rails_panel_copy": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int]),
     "rails_panel_axpy": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_int]),
+    "rails_sptrsv_create": (C.c_int, [_vp, C.c_int64, _i64p, _i32p, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "rails_sptrsv_destroy": (None, [_vp]),
+    "rails_sptrsv_levels": (C.c_int64, [_vp]),
+    "rails_sptrsv_solve": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
+    "rails_panel_permute_rows": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int]),
+    "rails_index_upload": (C.c_int, [_vp, _i32p, C.c_int64, C.POINTER(_vp)]),
+    "rails_index_free": (None, [_vp, _vp]),
     "rails_panel_random": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rails_gram": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _dp, C.c_int]),
     "rails_panel_gemm": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_double, _vp, C.c_int]),

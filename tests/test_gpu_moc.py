@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 PARAMS = {"Maximum iterations": 1000, "Tolerance": 1e-3, "Expand size": 3, "Lanczos iterations": 10}
 
 
-@pytest.mark.parametrize("subspace", [1, 0])
-def test_moc_schur_generalized_solve(subspace, oracle):
+@pytest.mark.parametrize("subspace,device_solve", [(1, False), (0, False), (1, True), (0, True)])
+def test_moc_schur_generalized_solve(subspace, device_solve, oracle):
     import rails_amd
     from rails_amd import problems as P
     from rails_amd.schur import SchurOperator
@@ -22,7 +22,7 @@ def test_moc_schur_generalized_solve(subspace, oracle):
     n = A.shape[0]
     A2, m2, B2 = add_border(A, mdiag, B)
     ctx = rails_amd.Context(device=0, seed=1)
-    S = SchurOperator(ctx, (A2.indptr.astype(np.int64), A2.indices.astype(np.int32), A2.data.astype(np.float64)), m2, tol=1e-12)
+    S = SchurOperator(ctx, (A2.indptr.astype(np.int64), A2.indices.astype(np.int32), A2.data.astype(np.float64)), m2, tol=1e-12, device_solve=device_solve)
     Sd, ms, BSd, i1, i2 = schur_dense(A2, m2, B2)
     assert S.m2 == 512 and np.array_equal(S.idx2, i2)
     np.testing.assert_allclose(S.dense(), Sd, atol=1e-10 * np.abs(Sd).max())
@@ -58,7 +58,10 @@ def test_moc_schur_generalized_solve(subspace, oracle):
     # recurrence (oracle/README.md), in which the residual estimates of two implementations part from the first trips on (measured: they
     # differ by more than 1e-6 at trip 1 on both back ends), so the trajectories cannot be compared trip by trip; what they reach agrees
     # (above).  Their lengths, measured (scripts/probe_bounds.py): oracle 575 trips, direct back end 499 (0.87x), coordinate-space back
-    # end 722 (1.26x) -- asserted with a margin of 10 % on those ratios.
-    assert out["trips"] / 1.4 <= s.trips() <= 1.4 * out["trips"]
+    # end 722 (1.26x) with the A11 solve on the host -- asserted with a margin of 10 % on those ratios; with the solve on the device (the
+    # same factors applied in another order of operations: a perturbation at rounding level) 541 (0.94x) and 862 (1.50x): bound 1.6.
+    print("MOC trips: oracle %d, subspace %d device_solve %d: %d; A11 levels %s" % (out["trips"], subspace, device_solve, s.trips(), S.dlu.levels() if S.dlu else None))
+    bound = 1.6 if device_solve else 1.4
+    assert out["trips"] / bound <= s.trips() <= bound * out["trips"]
     s.close()
     ctx.close()

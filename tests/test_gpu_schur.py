@@ -91,8 +91,66 @@ def test_rectangular_operators():
     ctx.close()
 
 
-@pytest.mark.parametrize("subspace", [1, 0])
-def test_schur_operator_and_solve(subspace):
+def test_sparse_triangular_solves_and_device_lu():
+    """rails_sptrsv_solve / DeviceLU (rails_amd/csrc/sptrsv.hip; what src/SchurOperator.cpp:193-200 does on the host with the KLU factors):
+    the L and U factors of scipy's SuperLU applied on the device against the host solve -- a random sparse matrix (few, wide levels), a
+    banded one (hundreds of narrow levels: the one-workgroup chain), both transposes, panel windows, widths 1..40."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    import rails_amd
+    from rails_amd.schur import DeviceLU
+    from rails_amd.wrappers import HipMultiVectorWrapper as MV
+
+    ctx = rails_amd.Context(device=0, seed=6)
+    g = np.random.default_rng(4)
+    cases = []
+    n = 1500
+    cases.append(("random", sp.random(n, n, density=4.0 / n, random_state=7, format="csc") + sp.identity(n, format="csc") * 3.0))
+    n = 900
+    band = sp.diags([g.uniform(-1, 1, n - abs(k)) for k in (-7, -2, -1, 0, 1, 3, 9)], (-7, -2, -1, 0, 1, 3, 9), format="lil")
+    band.setdiag(4.0 + g.uniform(0, 1, n))
+    cases.append(("banded", band.tocsc()))
+    cases.append(("tiny", sp.csc_matrix(np.array([[2.0]]))))
+    for name, A in cases:
+        n = A.shape[0]
+        lu = spla.splu(A.tocsc())
+        dlu = DeviceLU(ctx, lu)
+        lv = dlu.levels()
+        print(name, n, "levels", lv)
+        if name == "banded":
+            assert lv["L"] > 100 and lv["U"] > 100
+        for nc, off in ((1, 0), (5, 2), (16, 0), (40, 3)):
+            Bh = g.uniform(-1, 1, (n, nc))
+            big = MV(ctx, m=n, n=nc + off, capacity=nc + off + 2)
+            B = big.view(off, off + nc - 1)
+            B.from_host(Bh)
+            tmp, out = MV(ctx, m=n, n=nc, capacity=nc), MV(ctx, m=n, n=nc + 1, capacity=nc + 1)
+            for trans in (False, True):
+                dlu.solve(B, tmp, out.view(1, nc), trans=trans)
+                ref = lu.solve(Bh, trans="T" if trans else "N").reshape(n, nc)
+                got = out.view(1, nc).to_host()
+                assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (name, nc, trans, np.abs(got - ref).max())
+                assert np.array_equal(B.to_host(), Bh)  # the right-hand side is left alone
+        dlu.close()
+    # what the library refuses: an entry outside the triangle, a missing or zero diagonal, a stored diagonal of a unit triangle
+    import ctypes as C
+
+    def create(rp, ci, va, lower, unit):
+        h = C.c_void_p()
+        rp, ci, va = np.asarray(rp, np.int64), np.asarray(ci, np.int32), np.asarray(va, np.float64)
+        return ctx.lib.rails_sptrsv_create(ctx.h, rp.size - 1, rp.ctypes.data_as(C.POINTER(C.c_int64)), ci.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           va.ctypes.data_as(C.POINTER(C.c_double)), lower, unit, C.byref(h))
+
+    assert create([0, 2, 3], [0, 1, 1], [1.0, 2.0, 1.0], 1, 0) != 0  # (0, 1) in a lower triangle
+    assert create([0, 1, 2], [0, 0], [1.0, 2.0], 1, 0) != 0  # row 1 without a diagonal
+    assert create([0, 1, 2], [0, 1], [1.0, 0.0], 1, 0) != 0  # zero pivot
+    assert create([0, 1, 2], [0, 1], [1.0, 1.0], 1, 1) != 0  # unit triangle with its diagonal stored
+    ctx.close()
+
+
+@pytest.mark.parametrize("subspace,device_solve", [(1, True), (0, True), (1, False)])
+def test_schur_operator_and_solve(subspace, device_solve):
     import scipy.linalg as sl
 
     import rails_amd
@@ -101,7 +159,7 @@ def test_schur_operator_and_solve(subspace):
 
     A, Ad, mass, B, mask1 = _descriptor_system()
     ctx = rails_amd.Context(device=0, seed=4)
-    S = SchurOperator(ctx, A, mass)
+    S = SchurOperator(ctx, A, mass, device_solve=device_solve)
     i1, i2 = np.flatnonzero(mask1), np.flatnonzero(~mask1)
     assert np.array_equal(S.idx1, i1) and np.array_equal(S.idx2, i2)
     Sd = Ad[np.ix_(i2, i2)] - Ad[np.ix_(i2, i1)] @ np.linalg.solve(Ad[np.ix_(i1, i1)], Ad[np.ix_(i1, i2)])
@@ -113,8 +171,9 @@ def test_schur_operator_and_solve(subspace):
     Yt = S.op.transpose().apply(MV(ctx, data=Xh))
     np.testing.assert_allclose(Yt.to_host(), Sd.T @ Xh, atol=1e-12)
     assert S.applies == 10  # matrix-vector products through the operator, as SchurOperator::GetMVPs counts them
-    # X stayed on the device: per product only the m1 x nc block A12 X went to the host and the solution of the A11 system came back
-    assert S.host_bytes == 2 * 2 * S.m1 * 5 * 8 and S.m1 < S.m2
+    # X stayed on the device.  With the solve on the device nothing of a product crossed PCIe; with the host solve only the m1 x nc block
+    # A12 X went to the host and the solution of the A11 system came back
+    assert S.host_bytes == (0 if device_solve else 2 * 2 * S.m1 * 5 * 8) and S.m1 < S.m2
     # the Lyapunov equation on the Schur complement (what src/main.cpp:90-118 sets up): S X + X S' + B2 B2' = 0
     B2 = S.restrict(B)
     s = rails_amd.Solver(ctx, S.op, B2)
@@ -131,7 +190,7 @@ def test_schur_operator_and_solve(subspace):
     # a general nonsingular part of the mass matrix: S X D + D X S' + B2 B2' = 0 with D = diag(M22)
     mass2 = mass.copy()
     mass2[~mask1] = g.uniform(0.5, 1.5, (~mask1).sum())
-    S2 = SchurOperator(ctx, A, mass2)
+    S2 = SchurOperator(ctx, A, mass2, device_solve=device_solve)
     Dm = S2.mass22
     Mop = rails_amd.HipOperatorWrapper(ctx, np.arange(S2.m2 + 1, dtype=np.int64), np.arange(S2.m2, dtype=np.int32), Dm)
     s2 = rails_amd.Solver(ctx, S2.op, B2, M=Mop)
