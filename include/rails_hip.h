@@ -326,6 +326,9 @@ void rails_sb03md(char dico, char job, char fact, char trans, int n, double *A, 
                   double *scale, int *info);
 /* how many calls of this process took the squared-Smith route and the Bartels-Stewart route (diagnostics) */
 void rails_sb03md_counts(long *smith, long *schur);
+/* calls of the factored ADI form that built on the call before (a bordered extension of its matrix: shifts kept, LU factors extended)
+ * and calls that started from scratch */
+void rails_sb03md_adi_counts(long *extended, long *fresh);
 /* after an attempt of the squared-Smith route that did not apply, the calling thread skips the attempt for the next 30 calls;
  * this sets that counter (0: try again at the next call) */
 void rails_sb03md_set_pause(int calls);

@@ -101,6 +101,7 @@ SIGNATURES = {
     "rails_ctx_reserve_staging": (C.c_int, [_vp, C.c_size_t]),
     "rails_sb03md_set_pause": (None, [C.c_int]),
     "rails_sb03md_counts": (None, [C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "rails_sb03md_adi_counts": (None, [C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "rails_dtrsm": (None, [C.c_char, C.c_char, C.c_char, C.c_char, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int]),
     "rails_dgemm": (None, [C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int]),
     "rails_dpotrf": (None, [C.c_char, C.c_int, _dp, C.c_int, _ip]),
