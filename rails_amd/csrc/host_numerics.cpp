@@ -50,6 +50,7 @@ typedef void (*lp_dsyrk)(const char *, const char *, const int *, const int *, c
 typedef void (*lp_dgetrf)(const int *, const int *, double *, const int *, int *, int *);
 typedef void (*lp_dgetrs)(const char *, const int *, const int *, const double *, const int *, const int *, double *, const int *, int *);
 typedef void (*lp_dlaswp)(const int *, double *, const int *, const int *, const int *, const int *, const int *);
+typedef void (*lp_dgetri)(const int *, double *, const int *, const int *, double *, const int *, int *);
 }
 
 struct HostLapack {
@@ -71,6 +72,7 @@ struct HostLapack {
     lp_dgetrf dgetrf = nullptr; // optional: the squared-Smith fast path of rails_sb03md
     lp_dgetrs dgetrs = nullptr;
     lp_dlaswp dlaswp = nullptr; // optional: the bordered LU update of the factored ADI route
+    lp_dgetri dgetri = nullptr; // optional: explicit (M - p I)^-1 of the factored ADI route
 } g_lp;
 std::mutex g_lp_mutex;
 
@@ -130,6 +132,7 @@ bool try_open(const std::string &path)
     L.dgetrf = (lp_dgetrf)lookup(h, "dgetrf_");
     L.dgetrs = (lp_dgetrs)lookup(h, "dgetrs_");
     L.dlaswp = (lp_dlaswp)lookup(h, "dlaswp_");
+    L.dgetri = (lp_dgetri)lookup(h, "dgetri_");
     L.dpstrf = (lp_dpstrf)lookup(h, "dpstrf_");
     L.dgeqp3 = (lp_dgeqp3)lookup(h, "dgeqp3_");
     L.dorgqr = (lp_dorgqr)lookup(h, "dorgqr_");
@@ -518,6 +521,7 @@ struct AdiCache {
     std::vector<double> M, shift;
     std::vector<std::vector<double>> LUs;
     std::vector<std::vector<int>> ips;
+    std::vector<std::vector<double>> Inv; // explicit (M - p_i I)^-1 (n >= 64: see adi_lyapunov_lowrank_once)
 };
 static AdiCache &adi_cache()
 {
@@ -551,6 +555,61 @@ static bool extend_lu(int n1, int n, const std::vector<double> &LU1, const std::
     if (info != 0) return false;
     g_lp.dlaswp(&n1, A21, &n, &one, &nb, ip2.data(), &one);
     for (int j = 0; j < nb; ++j) ip[n1 + j] = ip2[j] + n1;
+    return true;
+}
+
+// In place: S <- S^-1 (n x n), through dgetrf + dgetri (or n solves with the identity)
+static bool invert_dense(int n, std::vector<double> &S)
+{
+    std::vector<int> ip(n);
+    int info = 0;
+    g_lp.dgetrf(&n, &n, S.data(), &n, ip.data(), &info);
+    if (info != 0) return false;
+    if (g_lp.dgetri) {
+        double wq = 0.0;
+        int lw = -1;
+        g_lp.dgetri(&n, S.data(), &n, ip.data(), &wq, &lw, &info);
+        lw = info == 0 ? std::max(n, (int)wq) : 64 * n;
+        std::vector<double> work((size_t)lw);
+        g_lp.dgetri(&n, S.data(), &n, ip.data(), work.data(), &lw, &info);
+        return info == 0;
+    }
+    std::vector<double> I((size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j) I[j + (size_t)j * n] = 1.0;
+    const char N = 'N';
+    g_lp.dgetrs(&N, &n, &n, S.data(), &n, ip.data(), I.data(), &n, &info);
+    S.swap(I);
+    return info == 0;
+}
+
+// S (n x n, holding the matrix on entry) <- S^-1, given the inverse J1 of its leading n1 x n1 block: with E = J1 A12, F = A21 J1,
+// C = (A22 - A21 E)^-1:  S^-1 = [J1 + E C F, -E C; -C F, C].  Four thin products and an (n - n1)-square inverse: (n - n1) / n of an inversion.
+static bool extend_inverse(int n1, int n, const std::vector<double> &J1, std::vector<double> &S)
+{
+    const int nb = n - n1;
+    if (nb == 0) {
+        S = J1;
+        return true;
+    }
+    const double d_one = 1.0, d_mone = -1.0, d_zero = 0.0;
+    double *A12 = &S[(size_t)n1 * n], *A21 = &S[n1], *A22 = &S[n1 + (size_t)n1 * n];
+    std::vector<double> E((size_t)n1 * nb), F((size_t)nb * n1), Cm((size_t)nb * nb), G((size_t)nb * n1);
+    g_lp.dgemm("N", "N", &n1, &nb, &n1, &d_one, J1.data(), &n1, A12, &n, &d_zero, E.data(), &n1);
+    g_lp.dgemm("N", "N", &nb, &n1, &n1, &d_one, A21, &n, J1.data(), &n1, &d_zero, F.data(), &nb);
+    for (int j = 0; j < nb; ++j)
+        for (int i = 0; i < nb; ++i) Cm[i + (size_t)j * nb] = A22[i + (size_t)j * n];
+    g_lp.dgemm("N", "N", &nb, &nb, &n1, &d_mone, A21, &n, E.data(), &n1, &d_one, Cm.data(), &nb);
+    if (!invert_dense(nb, Cm)) return false;
+    g_lp.dgemm("N", "N", &nb, &n1, &nb, &d_one, Cm.data(), &nb, F.data(), &nb, &d_zero, G.data(), &nb); // G = C F
+    // leading block: J1 + E G
+    for (int j = 0; j < n1; ++j) memcpy(&S[(size_t)j * n], &J1[(size_t)j * n1], sizeof(double) * n1);
+    g_lp.dgemm("N", "N", &n1, &n1, &nb, &d_one, E.data(), &n1, G.data(), &nb, &d_one, S.data(), &n);
+    // -E C, -G, C
+    g_lp.dgemm("N", "N", &n1, &nb, &nb, &d_mone, E.data(), &n1, Cm.data(), &nb, &d_zero, A12, &n);
+    for (int j = 0; j < n1; ++j)
+        for (int i = 0; i < nb; ++i) A21[i + (size_t)j * n] = -G[i + (size_t)j * nb];
+    for (int j = 0; j < nb; ++j)
+        for (int i = 0; i < nb; ++i) A22[i + (size_t)j * n] = Cm[i + (size_t)j * nb];
     return true;
 }
 
@@ -607,12 +666,19 @@ static bool adi_lyapunov_lowrank_once(bool tr, int n, const double *A, int lda, 
     // a bordered extension of the last matrix this thread solved for?  (see AdiCache)
     static const bool allow_inherit = !(getenv("RAILS_SB03MD_ADI_INHERIT") && atoi(getenv("RAILS_SB03MD_ADI_INHERIT")) == 0);
     AdiCache &cache = adi_cache();
-    bool inherit = allow_inherit && !from_scratch && g_lp.dlaswp && g_lp.dtrsm && cache.n >= 32 && cache.tr == tr && n >= cache.n && n - cache.n <= 64 && cache.L >= 1;
+    // From n = 64 on the step operators S_i = sqrt(p_i / p_i-1) [I + (p_i + p_i-1) (M - p_i I)^-1] are formed explicitly and a term is ONE
+    // product S_i Z with 16 columns: a pair of triangular solves with 16 right-hand sides runs at a third of that rate, and there are
+    // 20-odd terms (n = 177: 0.77 -> 0.23 ms).  An inversion costs more than a factorisation (0.3-0.4 ms per shift at n = 200), but inside a
+    // restart cycle the inverse is EXTENDED like the matrix (extend_inverse: four thin products); the residual fence judges the result.
+    static const bool allow_explicit = !(getenv("RAILS_SB03MD_ADI_INVERSE") && atoi(getenv("RAILS_SB03MD_ADI_INVERSE")) == 0);
+    const bool explicit_steps = allow_explicit && n >= 64;
+    bool inherit = allow_inherit && !from_scratch && g_lp.dlaswp && g_lp.dtrsm && cache.n >= 32 && cache.tr == tr && n >= cache.n && n - cache.n <= 64 && cache.L >= 1 &&
+                   (explicit_steps ? (int)cache.Inv.size() == cache.L : (int)cache.LUs.size() == cache.L);
     for (int j = 0; inherit && j < cache.n; ++j) inherit = memcmp(&M[(size_t)j * n], &cache.M[(size_t)j * cache.n], sizeof(double) * cache.n) == 0;
     double a = 0.0, b = 0.0;
     int L = 1;
     std::vector<double> shift;
-    std::vector<std::vector<double>> LUs;
+    std::vector<std::vector<double>> LUs, Inv;
     std::vector<std::vector<int>> ips;
     // extent of the spectrum along the real axis: b ~ largest modulus (power iteration), a ~ smallest (inverse iteration with the factors
     // of M - p I: the eigenvalue nearest p > 0 is the one of smallest modulus when the spectrum is near the negative real axis), six steps
@@ -623,7 +689,7 @@ static bool adi_lyapunov_lowrank_once(bool tr, int n, const double *A, int lda, 
         for (int i = 0; i < n; ++i) s2 += z[i] * z[i];
         return std::sqrt(s2);
     };
-    auto extent = [&](const std::vector<double> &LUp, const std::vector<int> &ipp, double pshift, double *a_out, double *b_out) {
+    auto extent = [&](const std::vector<double> &LUp, const std::vector<int> &ipp, const std::vector<double> *InvP, double pshift, double *a_out, double *b_out) {
         for (int i = 0; i < n; ++i) v[i] = 1.0 + 0.37 * std::sin(1.0 + 2.3 * i);
         double bmax = 0.0, amin = 0.0;
         for (int it = 0; it < 6; ++it) {
@@ -637,9 +703,14 @@ static bool adi_lyapunov_lowrank_once(bool tr, int n, const double *A, int lda, 
         for (int it = 0; it < 6; ++it) {
             const double nv = nrm(v);
             for (int i = 0; i < n; ++i) v[i] /= nv;
-            int inf = 0;
-            g_lp.dgetrs(&N, &n, &one, LUp.data(), &n, ipp.data(), v.data(), &n, &inf);
-            if (inf != 0) return false;
+            if (InvP) {
+                gemm('N', 'N', n, 1, n, InvP->data(), n, v.data(), n, u.data(), n);
+                v = u;
+            } else {
+                int inf = 0;
+                g_lp.dgetrs(&N, &n, &one, LUp.data(), &n, ipp.data(), v.data(), &n, &inf);
+                if (inf != 0) return false;
+            }
             amin = nrm(v); // -> 1 / |lambda - p|min
         }
         if (!(amin > 0.0) || !(bmax > 0.0) || !std::isfinite(amin) || !std::isfinite(bmax)) return false;
@@ -651,18 +722,22 @@ static bool adi_lyapunov_lowrank_once(bool tr, int n, const double *A, int lda, 
     };
     if (inherit) {
         a = cache.a, b = cache.b, L = cache.L, shift = cache.shift;
-        LUs.assign(L, std::vector<double>());
-        ips.assign(L, std::vector<int>());
+        LUs.assign(explicit_steps ? 0 : L, std::vector<double>());
+        ips.assign(explicit_steps ? 0 : L, std::vector<int>());
+        Inv.assign(explicit_steps ? L : 0, std::vector<double>());
         for (int i = 0; i < L && inherit; ++i) {
-            LUs[i] = M;
-            for (int j = 0; j < n; ++j) LUs[i][j + (size_t)j * n] -= shift[i];
-            inherit = extend_lu(cache.n, n, cache.LUs[i], cache.ips[i], LUs[i], ips[i]);
+            std::vector<double> &S = explicit_steps ? Inv[i] : LUs[i];
+            S = M;
+            for (int j = 0; j < n; ++j) S[j + (size_t)j * n] -= shift[i];
+            inherit = explicit_steps ? extend_inverse(cache.n, n, cache.Inv[i], S) : extend_lu(cache.n, n, cache.LUs[i], cache.ips[i], S, ips[i]);
         }
         lap(t_lu);
         // do the inherited shifts still cover the spectrum?  (after a restart it widens quickly as the space grows: shifts chosen for
         // [9.5, 19] took 32 terms, then did not converge at all, on a matrix whose spectrum had reached [1.3, 20])
         double a_now = 0.0, b_now = 0.0;
-        if (inherit && !(extent(LUs[0], ips[0], shift[0], &a_now, &b_now) && a_now >= 0.8 * a && b_now <= 1.15 * b)) inherit = false;
+        if (inherit && !((explicit_steps ? extent(Inv[0], std::vector<int>(), &Inv[0], shift[0], &a_now, &b_now) : extent(LUs[0], ips[0], nullptr, shift[0], &a_now, &b_now)) &&
+                         a_now >= 0.8 * a && b_now <= 1.15 * b))
+            inherit = false;
         lap(t_bounds);
     }
     if (!inherit) {
@@ -670,7 +745,7 @@ static bool adi_lyapunov_lowrank_once(bool tr, int n, const double *A, int lda, 
     std::vector<int> ip0(n);
     g_lp.dgetrf(&n, &n, LU0.data(), &n, ip0.data(), &info);
     if (info != 0) return false;
-    if (!extent(LU0, ip0, 0.0, &a, &b)) return false;
+    if (!extent(LU0, ip0, nullptr, 0.0, &a, &b)) return false;
     lap(t_bounds);
     if (b / a > 1e5) return false;
     // Wachspress' optimal real ADI parameters for [a, b]: with L = 2^s of them one sweep damps every mode by
@@ -703,13 +778,19 @@ static bool adi_lyapunov_lowrank_once(bool tr, int n, const double *A, int lda, 
         }
         std::sort(shift.begin(), shift.end());
     }
-    LUs.assign(L, std::vector<double>());
-    ips.assign(L, std::vector<int>(n));
+    LUs.assign(explicit_steps ? 0 : L, std::vector<double>());
+    ips.assign(explicit_steps ? 0 : L, std::vector<int>(n));
+    Inv.assign(explicit_steps ? L : 0, std::vector<double>());
     for (int i = 0; i < L; ++i) {
-        LUs[i] = M;
-        for (int j = 0; j < n; ++j) LUs[i][j + (size_t)j * n] -= shift[i];
-        g_lp.dgetrf(&n, &n, LUs[i].data(), &n, ips[i].data(), &info);
-        if (info != 0) return false;
+        std::vector<double> &S = explicit_steps ? Inv[i] : LUs[i];
+        S = M;
+        for (int j = 0; j < n; ++j) S[j + (size_t)j * n] -= shift[i];
+        if (explicit_steps) {
+            if (!invert_dense(n, S)) return false;
+        } else {
+            g_lp.dgetrf(&n, &n, S.data(), &n, ips[i].data(), &info);
+            if (info != 0) return false;
+        }
     }
     lap(t_lu);
     }
@@ -725,9 +806,22 @@ static bool adi_lyapunov_lowrank_once(bool tr, int n, const double *A, int lda, 
         for (size_t q = 0; q < blk; ++q) s2 += z[q] * z[q];
         return s2;
     };
-    T = F;
-    g_lp.dgetrs(&N, &n, &rank, LUs[0].data(), &n, ips[0].data(), T.data(), &n, &info);
-    if (info != 0) return false;
+    // the step operators of the explicit form (the inverses themselves are what the next call extends: they are kept as they are)
+    std::vector<std::vector<double>> Sm(explicit_steps ? L : 0);
+    for (int i = 0; i < (int)Sm.size(); ++i) {
+        const double pj = shift[i], pp = shift[(i + L - 1) % L];
+        const double f = std::sqrt(pj / pp), fg = f * (pj + pp);
+        Sm[i].resize(nn);
+        for (size_t q = 0; q < nn; ++q) Sm[i][q] = fg * Inv[i][q];
+        for (int j = 0; j < n; ++j) Sm[i][j + (size_t)j * n] += f;
+    }
+    if (explicit_steps)
+        gemm('N', 'N', n, rank, n, Inv[0].data(), n, F.data(), n, T.data(), n);
+    else {
+        T = F;
+        g_lp.dgetrs(&N, &n, &rank, LUs[0].data(), &n, ips[0].data(), T.data(), &n, &info);
+        if (info != 0) return false;
+    }
     {
         const double f = std::sqrt(2.0 * shift[0]);
         for (size_t q = 0; q < blk; ++q) T[q] *= f;
@@ -739,11 +833,15 @@ static bool adi_lyapunov_lowrank_once(bool tr, int n, const double *A, int lda, 
         const int cur = j % L, prv = (j - 1) % L;
         const double pj = shift[cur], pp = shift[prv];
         const double *zp = Z.data() + (size_t)(j - 1) * blk;
-        std::copy(zp, zp + blk, T.begin());
-        g_lp.dgetrs(&N, &n, &rank, LUs[cur].data(), &n, ips[cur].data(), T.data(), &n, &info);
-        if (info != 0) return false;
-        const double f = std::sqrt(pj / pp), g = pj + pp;
-        for (size_t q = 0; q < blk; ++q) T[q] = f * (zp[q] + g * T[q]);
+        if (explicit_steps)
+            gemm('N', 'N', n, rank, n, Sm[cur].data(), n, zp, n, T.data(), n);
+        else {
+            std::copy(zp, zp + blk, T.begin());
+            g_lp.dgetrs(&N, &n, &rank, LUs[cur].data(), &n, ips[cur].data(), T.data(), &n, &info);
+            if (info != 0) return false;
+            const double f = std::sqrt(pj / pp), g = pj + pp;
+            for (size_t q = 0; q < blk; ++q) T[q] = f * (zp[q] + g * T[q]);
+        }
         const double n2 = norm2(T.data());
         if (!std::isfinite(n2) || n2 > 1e4 * total) return false; // M is not stable
         if ((int)((size_t)(j + 1) * rank) > max_cols) return false;
@@ -805,6 +903,7 @@ static bool adi_lyapunov_lowrank_once(bool tr, int n, const double *A, int lda, 
     cache.shift.swap(shift);
     cache.LUs.swap(LUs);
     cache.ips.swap(ips);
+    cache.Inv.swap(Inv);
     return true;
 }
 

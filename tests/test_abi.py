@@ -200,6 +200,63 @@ def test_host_sb03md_smith_route_is_verified_and_falls_back():
         assert np.linalg.norm(X - Xref) <= 1e-8 * np.linalg.norm(Xref)  # conditioning of these problems, same algorithm on both sides
 
 
+def test_host_sb03md_builds_on_the_call_before_inside_a_restart_cycle():
+    """Inside a restart cycle the solver's projected matrix grows by bordering (V'AV keeps its leading block, src/LyapunovSolver.hpp:146-160):
+    the factored ADI route of rails_sb03md then keeps its shifts and EXTENDS the inverses / LU factors of M - p I of the call before instead
+    of recomputing them (host_numerics.cpp, AdiCache).  The same projected equations, solved in the order a run meets them, have to come
+    out as Bartels-Stewart gives them whether a call inherited or not; a border that moves the spectrum, an unrelated matrix and a smaller
+    one must not be served from the cache."""
+    import scipy.linalg as sl
+
+    import rails_amd
+
+    lib = rails_amd.load()
+    dp = C.POINTER(C.c_double)
+
+    def counts():
+        a, b = C.c_long(0), C.c_long(0)
+        lib.rails_sb03md_adi_counts(C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def solve(A, Bm):
+        n = A.shape[0]
+        Ap, X = np.asfortranarray(A.copy()), np.asfortranarray(-(Bm @ Bm.T))
+        scale, info = C.c_double(0), C.c_int(0)
+        lib.rails_sb03md(b"C", b"X", b"N", b"T", n, Ap.ctypes.data_as(dp), n, X.ctypes.data_as(dp), n, C.byref(scale), C.byref(info))
+        assert info.value == 0 and scale.value == 1.0
+        ref = sl.solve_continuous_lyapunov(A, -(Bm @ Bm.T))
+        return np.abs(X - ref).max() / np.abs(ref).max()
+
+    g = np.random.default_rng(3)
+    N = 208
+    Afull = -3.0 * np.eye(N) + 0.8 * g.standard_normal((N, N)) / np.sqrt(N)
+    Bfull = g.standard_normal((N, 16))
+    lib.rails_sb03md_set_pause(0)
+    e0, f0 = counts()
+    sizes = [48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 208]  # 48 -> 64: from the LU form to the explicit step operators (a fresh start)
+    for n in sizes:
+        assert solve(Afull[:n, :n], Bfull[:n]) <= 1e-11, n
+    e1, f1 = counts()
+    assert e1 - e0 >= len(sizes) - 3 and f1 - f0 >= 2  # (the first call, and the first one of the explicit form, start from scratch)
+    # the same matrix again (a second right-hand side): served from the cache
+    assert solve(Afull, g.standard_normal((N, 16))) <= 1e-11
+    assert counts()[0] == e1 + 1
+    # a border that widens the spectrum by two orders of magnitude: the inherited shifts do not cover it, the call starts from scratch
+    Aw = np.zeros((N + 16, N + 16))
+    Aw[:N, :N] = Afull
+    Aw[N:, N:] = -0.03 * np.eye(16)
+    Aw[:N, N:] = 0.01 * g.standard_normal((N, 16))
+    Aw[N:, :N] = 0.01 * g.standard_normal((16, N))
+    e2, f2 = counts()
+    assert solve(Aw, g.standard_normal((N + 16, 16))) <= 1e-10
+    assert counts() == (e2, f2 + 1)
+    # an unrelated matrix of the next size, and a smaller matrix: nothing to build on
+    A2 = -2.0 * np.eye(N + 32) + 0.5 * g.standard_normal((N + 32, N + 32)) / np.sqrt(N + 32)
+    assert solve(A2, g.standard_normal((N + 32, 16))) <= 1e-11
+    assert solve(A2[:100, :100], g.standard_normal((100, 16))) <= 1e-11
+    assert counts() == (e2, f2 + 3)
+
+
 def test_host_sb03md_at_the_c4_size():
     """The projected equation at BASELINE configs[3]'s size (Restart size 256, B m x 32): V'AV of a nonsymmetric 27-point stencil operator
     on a 256-dimensional block Krylov space, right-hand side -(V'B)(V'B)' of rank 32.  Bartels-Stewart costs 21 ms there
