@@ -1,3 +1,7 @@
+"""Diagnostic (under tests/ because it uses the CPU oracle): the projected matrices V'AV and V'BB'V of both HIP back ends, one trip from the
+oracle's V after j trips of configs[1] at reduced size, against numpy (RAILS_DEBUG_DUMP_PROJECTED) -- how the round-2 deviation of the
+coordinate-space back end was traced to its device basis.
+    PYTHONPATH=. python tests/diag_projected.py        (on the GPU box)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -159,7 +159,7 @@ def test_solver_full_size_both_back_ends(ctx, c3):
         assert k <= PARAMS["Restart size"]
         assert np.abs(T - T.T).max() <= 1e-12 * np.abs(T).max()
         Vd = MV(ctx, data=V)
-        # the reference does not re-orthogonalise after restarts (:270) either.  Measured (scripts/probe_bounds.py, three seeds): 3e-15 .. 5e-15
+        # the reference does not re-orthogonalise after restarts (:270) either.  Measured (tests/diag_bounds.py, three seeds): 3e-15 .. 5e-15
         # on the coordinate-space back end; 0.07e-10 .. 1.2e-10 on the direct one, whose restarts rotate V in place with the hand-written
         # panel GEMM (the vendor GEMM is opt-in since round 3 and no test asks for it) -- the CholQR of the nearly dependent A*V blocks
         # sets that level, the rotation preserves it

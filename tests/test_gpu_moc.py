@@ -57,7 +57,7 @@ def test_moc_schur_generalized_solve(subspace, device_solve, oracle):
     # Several hundred trips of a slowly converging solve with `Lanczos iterations` (10) > 2 + p: the chaotic regime of the reference's own
     # recurrence (oracle/README.md), in which the residual estimates of two implementations part from the first trips on (measured: they
     # differ by more than 1e-6 at trip 1 on both back ends), so the trajectories cannot be compared trip by trip; what they reach agrees
-    # (above).  Their lengths, measured (scripts/probe_bounds.py): oracle 575 trips, direct back end 499 (0.87x), coordinate-space back
+    # (above).  Their lengths, measured (tests/diag_bounds.py): oracle 575 trips, direct back end 499 (0.87x), coordinate-space back
     # end 722 (1.26x) with the A11 solve on the host -- asserted with a margin of 10 % on those ratios; with the solve on the device (the
     # same factors applied in another order of operations: a perturbation at rounding level) 541 (0.94x) and 862 (1.50x): bound 1.6.
     print("MOC trips: oracle %d, subspace %d device_solve %d: %d; A11 levels %s" % (out["trips"], subspace, device_solve, s.trips(), S.dlu.levels() if S.dlu else None))
