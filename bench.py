@@ -451,6 +451,8 @@ def main():
     _sm, _bs = _C.c_long(0), _C.c_long(0)
     rails_amd.load().rails_sb03md_counts(_C.byref(_sm), _C.byref(_bs))
     sb_counts = (int(_sm.value), int(_bs.value))
+    _ext, _fresh = _C.c_long(0), _C.c_long(0)
+    rails_amd.load().rails_sb03md_adi_counts(_C.byref(_ext), _C.byref(_fresh))
     hist = solver.history()
     log("[rank %d] host sections (s, whole solve incl. warm-up): %s" % (rank, json.dumps(solver.profile())))
     median_trip_ms = None
@@ -619,7 +621,9 @@ def main():
                        # solve, Lanczos on coordinates, restart algebra); device_critical = sections in which it waits for the device (A * W:
                        # materialise, SpMM, first projection round); the rest of the device's work runs behind the host's
                        "host_ms": host_ms, "device_critical_ms": device_critical_ms, "sections_ms_per_trip": sections_ms,
-                       "host_projected_solve_routes": {"smith_or_adi": sb_counts[0], "bartels_stewart": sb_counts[1]}},
+                       "host_projected_solve_routes": {"smith_or_adi": sb_counts[0], "bartels_stewart": sb_counts[1],
+                                                       # ADI calls that built on the call before (bordered matrix: shifts kept, inverses extended) / from scratch
+                                                       "adi_extended": int(_ext.value), "adi_from_scratch": int(_fresh.value)}},
             "roofline": {"bound": "hbm", "kernel": spmm_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale, "algorithmic_bytes": alg_bytes, "avg_ms": spmm_ms,
                          "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, corrected as profiles/README.md says)" if traffic else None,
