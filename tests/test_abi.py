@@ -218,13 +218,13 @@ def test_host_sb03md_builds_on_the_call_before_inside_a_restart_cycle():
         lib.rails_sb03md_adi_counts(C.byref(a), C.byref(b))
         return a.value, b.value
 
-    def solve(A, Bm):
+    def solve(A, Bm, trans=b"T"):
         n = A.shape[0]
         Ap, X = np.asfortranarray(A.copy()), np.asfortranarray(-(Bm @ Bm.T))
         scale, info = C.c_double(0), C.c_int(0)
-        lib.rails_sb03md(b"C", b"X", b"N", b"T", n, Ap.ctypes.data_as(dp), n, X.ctypes.data_as(dp), n, C.byref(scale), C.byref(info))
+        lib.rails_sb03md(b"C", b"X", b"N", trans, n, Ap.ctypes.data_as(dp), n, X.ctypes.data_as(dp), n, C.byref(scale), C.byref(info))
         assert info.value == 0 and scale.value == 1.0
-        ref = sl.solve_continuous_lyapunov(A, -(Bm @ Bm.T))
+        ref = sl.solve_continuous_lyapunov(A if trans == b"T" else A.T, -(Bm @ Bm.T))  # 'T': A X + X A' = C, 'N': A' X + X A = C
         return np.abs(X - ref).max() / np.abs(ref).max()
 
     g = np.random.default_rng(3)
@@ -255,6 +255,12 @@ def test_host_sb03md_builds_on_the_call_before_inside_a_restart_cycle():
     assert solve(A2, g.standard_normal((N + 32, 16))) <= 1e-11
     assert solve(A2[:100, :100], g.standard_normal((100, 16))) <= 1e-11
     assert counts() == (e2, f2 + 3)
+    # the other form of the equation (A' X + X A = C) on its own bordered sequence: the cache is kept per form
+    e3, f3 = counts()
+    for n in (96, 112, 128, 144):
+        assert solve(Afull[:n, :n], Bfull[:n], trans=b"N") <= 1e-11, n
+    e4, f4 = counts()
+    assert e4 - e3 == 3 and f4 - f3 == 1
 
 
 def test_host_sb03md_at_the_c4_size():
