@@ -15,7 +15,7 @@ run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACT
 run fetch FETCH_SIZE &&
 run write WRITE_SIZE GRBM_GUI_ACTIVE || exit 1
 python3 - <<'PY'
-import csv, glob, os, collections
+import csv, glob, os, collections, re
 O=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/dense_pmc"
 for d in sorted(glob.glob(O+"/*")):
     if not os.path.isdir(d): continue
@@ -23,8 +23,9 @@ for d in sorted(glob.glob(O+"/*")):
     for f in glob.glob(d+"/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             n=r["Kernel_Name"]
-            if any(t in n for t in ("k_gram_cols","k_update_gram","k_panel_gemm<")):
-                acc[n.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            m=re.search(r"(k_gram_cols|k_update_gram|k_panel_gemm)<[^>]*>", n)
+            if m:
+                acc[m.group(0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in acc.items():
         print(os.path.basename(d), k, {c: "%.4g (n=%d)"%(sum(x)/len(x),len(x)) for c,x in v.items()})
 PY
