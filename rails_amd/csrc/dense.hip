@@ -54,23 +54,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-    bool xok[TI], yok[TJ];
+    // Loads without branches (a load inside a conditional gets its own exec-masked block, and the compiler then waits for ALL loads in
+    // flight -- the next step's too -- before the first MFMA: see k_gram_cols): columns outside the operands are clamped to the tile's
+    // first column (their results are never written), rows past the slab to its last row with the Y operand zeroed.
+    int xoff[TI], yoff[TJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i) xok[i] = (xcol0 + 16 * i + li) < a;
+    for (int i = 0; i < TI; ++i) xoff[i] = (xcol0 + 16 * i + li) < a ? xcol0 + 16 * i + li : 0;
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) yok[j] = (ycol0 + 16 * j + li) < b;
+    for (int j = 0; j < TJ; ++j) yoff[j] = (ycol0 + 16 * j + li) < b ? ycol0 + 16 * j + li : 0;
 
     // software pipeline: the operands of the next 4-row step are in flight while the MFMAs of this one run (one step's loads per
     // wave do not cover the HBM latency at 3 waves per SIMD: the Gram at 17 columns ran at 37 % of the HBM rate without it)
     auto fetch = [&](int64_t r, double *xa, double *yb) {
         const int64_t row = r + kk;
         const bool rok = row < r_end;
-        const double *xr = X + row * ldx + xcol0 + li;
-        const double *yr = Y + row * ldy + ycol0 + li;
+        const int64_t rc = rok ? row : (r_end > 0 ? r_end - 1 : 0);
+        const double *xr = X + rc * ldx;
+        const double *yr = Y + rc * ldy;
 #pragma unroll
-        for (int i = 0; i < TI; ++i) xa[i] = (rok && xok[i]) ? xr[16 * i] : 0.0;
+        for (int i = 0; i < TI; ++i) xa[i] = xr[xoff[i]];
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) yb[j] = (rok && yok[j]) ? yr[16 * j] : 0.0;
+        for (int j = 0; j < TJ; ++j) {
+            const double t = yr[yoff[j]];
+            yb[j] = rok ? t : 0.0;
+        }
     };
     double xa[TI], yb[TJ], xn[TI], yn[TJ];
     int64_t r = r_begin + 4 * wave;
@@ -158,23 +165,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int q = 0; q < (NE > 0 ? NE : 1); ++q) acce[i][q] = 0.0;
-    bool xok[TI], yok[TJ];
+    // Loads without branches and without selects on X: with `cond ? load : 0` every load sat in an exec-masked block of its own and the
+    // compiler waited for everything in flight (`s_waitcnt vmcnt(0)`: the next step's operands too) before the first MFMA of a step.
+    // Columns outside the operands are clamped to column 0 (their results are never written), rows past the slab to its last row
+    // with the Y operand zeroed: what comes back from there is multiplied by zero.
+    int xoff[TI], yoff[TJ], eoff[NE > 0 ? NE : 1];
 #pragma unroll
-    for (int i = 0; i < TI; ++i) xok[i] = (xcol0 + 16 * i + li) < a;
+    for (int i = 0; i < TI; ++i) xoff[i] = (xcol0 + 16 * i + li) < a ? xcol0 + 16 * i + li : 0;
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) yok[j] = (16 * j + li) < b;
+    for (int j = 0; j < TJ; ++j) yoff[j] = (16 * j + li) < b ? 16 * j + li : 0;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) eoff[q] = 16 * TJ + q < b ? 16 * TJ + q : 0;
 
     auto fetch = [&](int64_t r, double *xa, double *yb, double *ye) {
         const int64_t row = r + kk;
         const bool rok = row < r_end;
-        const double *xr = X + row * ldx + xcol0 + li;
-        const double *yr = Y + row * ldy + li;
+        const int64_t rc = rok ? row : (r_end > 0 ? r_end - 1 : 0);
+        const double *xr = X + rc * ldx;
+        const double *yr = Y + rc * ldy;
 #pragma unroll
-        for (int i = 0; i < TI; ++i) xa[i] = (rok && xok[i]) ? xr[16 * i] : 0.0;
+        for (int i = 0; i < TI; ++i) xa[i] = xr[xoff[i]];
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) yb[j] = (rok && yok[j]) ? yr[16 * j] : 0.0;
+        for (int j = 0; j < TJ; ++j) {
+            const double t = yr[yoff[j]];
+            yb[j] = rok ? t : 0.0;
+        }
 #pragma unroll
-        for (int q = 0; q < NE; ++q) ye[q] = (rok && 16 * TJ + q < b) ? Y[row * ldy + 16 * TJ + q] : 0.0; // (one address per row: a broadcast)
+        for (int q = 0; q < NE; ++q) {
+            const double t = yr[eoff[q]]; // (one address per row: a broadcast; a column past b is clamped and its result dropped)
+            ye[q] = rok ? t : 0.0;
+        }
     };
     auto work = [&](const double *xa, const double *yb, const double *ye) {
 #pragma unroll

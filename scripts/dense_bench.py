@@ -43,6 +43,12 @@ def main():
             fn()
             samples.append(ctx.timer_stop())
         ms = float(np.median(samples))
+        # the same calls back to back inside ONE pair of events (no host round trip between them)
+        ctx.timer_start()
+        for _ in range(args.reps):
+            fn()
+        burst = ctx.timer_stop() / args.reps
+        note = (note + "; " if note else "") + "back to back: %.4f ms per call" % burst
         print(json.dumps({"case": name, "ms": round(ms, 4), "alg_GB": round(bytes_alg / 1e9, 3), "GBs": round(bytes_alg / ms / 1e6, 1),
                           "frac_hbm_8TBs": round(bytes_alg / ms / 1e6 / 8000.0, 3), "TFLOPs": round(flops / ms / 1e9, 2),
                           "frac_mfma_78TF": round(flops / ms / 1e9 / 78.0, 3), "note": note}), flush=True)
