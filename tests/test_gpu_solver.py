@@ -227,6 +227,29 @@ def test_coordinate_space_basis_stays_orthonormal_through_degenerate_blocks(ctx,
         assert np.linalg.norm(Xg - Xo) / np.linalg.norm(Xo) <= 1e-10
 
 
+def test_coordinate_space_basis_stays_orthonormal_over_a_long_run(ctx, monkeypatch):
+    """The same self-check over 150 trips and two dozen restarts of a stagnating solve (7-point Laplacian, tolerance out of reach), with the
+    overlapped block orthogonalisation at work: every block the device finishes behind the host's back is measured at its read-back.
+    (The round-2 rule of thumb for what goes wrong here: a looser re-orthogonalisation rule gave V'V - I of 1e-14, 2e-12, 6e-7, 0.9 after
+    50, 100, 200, 400 trips -- SubspaceWrappers.hpp, absorb_tail.)"""
+    from rails_amd import problems as P
+
+    monkeypatch.setenv("RAILS_SUBSPACE_VERIFY", "1")
+    A = P.laplace7(30, 30, 20)
+    m = A[0].size - 1
+    B = P.rhs(m, 8, seed=2)
+    params = {"Restart size": 96, "Reduced size": 48, "Expand size": 8, "Lanczos iterations": 12, "Tolerance": 1e-14, "Maximum iterations": 150}
+    code, V, T, s = _solve(ctx, A, B, params, seed=3, options={"subspace": 1})
+    st = s.backend_stats()
+    print({k: st[k] for k in ("dim", "absorb", "overlapped_blocks", "one_by_one", "compress", "verify_representation", "verify_orthonormality")})
+    assert code != 0 and s.trips() == 150  # (the tolerance is out of reach on purpose)
+    assert st["verified"] == 1 and st["overlapped_blocks"] >= 100 and st["compress"] >= 10
+    assert st["verify_orthonormality"] <= 1e-12 and st["verify_representation"] <= 1e-11  # measured 1e-14 / 1e-15
+    Q = V.T @ V
+    assert np.abs(Q - np.eye(Q.shape[0])).max() <= 1e-12
+    s.close()
+
+
 def test_config1_dense_m256_trajectory(ctx, oracle):
     # same matrix, B m x 8 and Lanczos iterations 8 <= 2 + p: the whole trajectory must match the oracle
     from rails_amd import problems as P
