@@ -76,20 +76,22 @@ int columnwise(rails_ctx *c, rails_panel *V, int from, int to)
     return RAILS_OK;
 }
 
-// Fallback after the block projection against the old columns has already been applied to all new columns:
-// Gram-Schmidt column by column INSIDE the block (m x w traffic only).  A column that loses more than 5 digits in
-// that step is numerically in the span of its predecessors; it gets the reference's full treatment (normalise,
-// project twice on all previous columns including the old ones, normalise), which is what the reference would have
-// made of it.
+// Fallback after the block projection against the old columns has already been applied to all new columns: Gram-Schmidt column by
+// column, each column twice against ALL columns before it -- the old ones included.  (Until round 3 the two passes ran inside the
+// block only, m x w traffic, and a column got the full treatment only when it lost more than five digits there.  A column that keeps a
+// fraction f of its length inherits the defects of the block's earlier columns against the old ones magnified by 1 / f, and a chain of
+// nearly dependent columns compounds that: the coordinate-space back end's copy of this shortcut cost it eight digits of V'AV on
+// BASELINE configs[1], DESIGN.md section 5 (vi).  This path is rare -- the repair round takes the rank-deficient blocks -- so it pays the
+// reference's price: src/StlWrapper.cpp:308-319.)
 int columnwise_in_block(rails_ctx *c, rails_panel *V, int k_old, int w)
 {
     for (int i = k_old; i < k_old + w; ++i) {
         double n0 = 0.0, n1 = 0.0;
         RAILS_TRY(column_norm(c, V, i, &n0));
         if (n0 > 0.0) RAILS_TRY(rails_panel_scale(c, V, i, 1, 1.0 / n0));
-        for (int pass = 0; pass < 2; ++pass) RAILS_TRY(project_column(c, V, i, k_old, i));
+        for (int pass = 0; pass < 2; ++pass) RAILS_TRY(project_column(c, V, i, 0, i));
         RAILS_TRY(column_norm(c, V, i, &n1));
-        if (!(n1 > 1e-5)) { // the column was normalised before the projection: n1 is the fraction that survived
+        if (!(n1 > 1e-5)) { // the column was normalised before the projection: n1 is the fraction that survived -- once more, from unit length
             RAILS_TRY(rails_panel_scale(c, V, i, 1, 1.0 / n1));
             for (int pass = 0; pass < 2; ++pass) RAILS_TRY(project_column(c, V, i, 0, i));
             RAILS_TRY(column_norm(c, V, i, &n1));
